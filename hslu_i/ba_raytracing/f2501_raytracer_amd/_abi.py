@@ -1,0 +1,144 @@
+"""ctypes mirror of include/rt_hip.h (structures only; no library is loaded here)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+RT_ABI_VERSION = 1
+RT_OK = 0
+RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OOM, RT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+RT_FLAG_REFLECTIONS, RT_FLAG_REFRACTIONS, RT_FLAG_BACKFACE_CULLING, RT_FLAG_ANTI_ALIASING = 1, 2, 4, 8
+RT_TRAVERSAL_BVH, RT_TRAVERSAL_LINEAR = 0, 1
+
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint32)
+_ip = C.POINTER(C.c_int32)
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("n_spheres", C.c_uint32), ("sphere_center", _fp), ("sphere_r_sq", _fp), ("sphere_r_inv", _fp),
+        ("sphere_material", _up),
+        ("n_triangles", C.c_uint32), ("tri_v1", _fp), ("tri_e1", _fp), ("tri_e2", _fp), ("tri_normal", _fp),
+        ("tri_material", _up),
+        ("n_materials", C.c_uint32), ("materials", _fp),
+        ("n_lights", C.c_uint32), ("lights", _fp),
+    ]
+
+
+class rt_params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+        ("focus", C.c_float * 3), ("fw", C.c_float), ("fh", C.c_float), ("fd", C.c_float),
+        ("eps_distance", C.c_float), ("air_ior", C.c_float), ("ambient", C.c_float),
+        ("flags", C.c_uint32),
+        ("aa_rays", C.c_uint32), ("aa_offsets", _fp),
+        ("light_mult", C.c_uint32), ("cloud_seed", C.c_uint32), ("n_cloud_sets", C.c_uint32), ("cloud_sets", _fp),
+        ("max_depth_reflection", C.c_uint32), ("max_depth_refraction", C.c_uint32),
+        ("win_x0", C.c_uint32), ("win_y0", C.c_uint32), ("win_w", C.c_uint32), ("win_h", C.c_uint32),
+        ("tile_size", C.c_uint32), ("n_ranks", C.c_uint32), ("rank", C.c_uint32),
+        ("traversal", C.c_uint32),
+    ]
+
+
+class rt_aux(C.Structure):
+    _fields_ = [("rgb", C.c_void_p), ("hit_id", C.c_void_p), ("hit_t", C.c_void_p)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [
+        ("rays_primary", C.c_uint64), ("rays_reflection", C.c_uint64), ("rays_refraction", C.c_uint64),
+        ("rays_shadow", C.c_uint64), ("pixels_written", C.c_uint64),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rt_bvh_info(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
+        ("bytes_nodes", C.c_uint64), ("bytes_triangles", C.c_uint64),
+    ]
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_fp)
+
+
+def uptr(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_up)
+
+
+def make_scene_desc(flat):
+    """flat: FlatScene (contiguous).  Returns (desc, keepalive)."""
+    f = flat.contiguous()
+    d = rt_scene_desc()
+    d.abi_version = RT_ABI_VERSION
+    d.n_spheres = f.n_spheres
+    d.sphere_center, d.sphere_r_sq, d.sphere_r_inv = fptr(f.sphere_center), fptr(f.sphere_r_sq), fptr(f.sphere_r_inv)
+    d.sphere_material = uptr(f.sphere_material)
+    d.n_triangles = f.n_triangles
+    d.tri_v1, d.tri_e1, d.tri_e2, d.tri_normal = fptr(f.tri_v1), fptr(f.tri_e1), fptr(f.tri_e2), fptr(f.tri_normal)
+    d.tri_material = uptr(f.tri_material)
+    d.n_materials = int(f.materials.shape[0])
+    d.materials = fptr(f.materials)
+    d.n_lights = int(f.lights.shape[0])
+    d.lights = fptr(f.lights)
+    return d, f
+
+
+def make_params(cfg, aa_offsets=None, cloud=None, window=None, n_ranks=1, rank=0, traversal=RT_TRAVERSAL_BVH):
+    """cfg: RenderConfig.  Returns (params, keepalive)."""
+    from . import sampling
+
+    p = rt_params()
+    p.abi_version = RT_ABI_VERSION
+    p.width, p.height = cfg.width, cfg.height
+    fo = cfg.focus
+    p.focus[0], p.focus[1], p.focus[2] = float(fo.x), float(fo.y), float(fo.z)
+    p.fw, p.fh, p.fd = float(cfg.fw), float(cfg.fh), float(cfg.fd)
+    p.eps_distance = float(cfg.eps_distance)
+    p.air_ior = float(cfg.air_ior)
+    p.ambient = float(cfg.ambient)
+    flags = 0
+    if cfg.has("reflections"):
+        flags |= RT_FLAG_REFLECTIONS
+    if cfg.has("refractions"):
+        flags |= RT_FLAG_REFRACTIONS
+    if cfg.has("backface_culling"):
+        flags |= RT_FLAG_BACKFACE_CULLING
+    keep = []
+    if cfg.has("anti_aliasing"):
+        flags |= RT_FLAG_ANTI_ALIASING
+        if aa_offsets is None:
+            aa_offsets = sampling.aa_offsets(cfg)
+        aa_offsets = np.ascontiguousarray(aa_offsets, np.float32)
+        p.aa_rays = int(aa_offsets.shape[0])
+        p.aa_offsets = fptr(aa_offsets)
+        keep.append(aa_offsets)
+    p.flags = flags
+    n = cfg.point_light_multiplicator
+    p.light_mult = n
+    p.cloud_seed = int(cfg.cloud_seed) & 0xFFFFFFFF
+    if n > 1:
+        if cloud is None:
+            cloud = sampling.cloud_sets(cfg)
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        assert cloud.shape[1] == n and cloud.shape[2] == 3
+        p.n_cloud_sets = int(cloud.shape[0])
+        p.cloud_sets = fptr(cloud)
+        keep.append(cloud)
+    p.max_depth_reflection = cfg.max_depth_reflection
+    p.max_depth_refraction = cfg.max_depth_refraction
+    if window is not None:
+        p.win_x0, p.win_y0, p.win_w, p.win_h = (int(v) for v in window)
+    p.tile_size = cfg.render_stride
+    p.n_ranks, p.rank = int(n_ranks), int(rank)
+    p.traversal = int(traversal)
+    return p, keep

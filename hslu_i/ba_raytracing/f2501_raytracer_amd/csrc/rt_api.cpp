@@ -1,0 +1,407 @@
+// rt_api.cpp -- the C ABI of include/rt_hip.h over the HIP runtime.
+//
+// rt_scene owns the device copies of the flattened Scene (reference src/scene/scene.rs:24-27), the
+// BVH, and reusable device workspaces (parameter tables, counters, per-thread path stack), so a
+// render call performs no allocation when its shape repeats (graph-capture friendly: rt_render_device
+// only enqueues async work on the caller's stream).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s", #expr, \
+                  hipGetErrorString(e_));                                                      \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return RT_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(RT_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return RT_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct rt_scene {
+  int device = 0;
+  RtDevScene dev{};
+  rt_bvh_info info{};
+  DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes;
+  // per-render workspaces
+  DevBuf aa, cloud, counters, path, fb, aux_rgb, aux_id, aux_t;
+  // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
+  std::vector<float> aa_host, cloud_host;
+};
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
+                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->path, &s->fb, &s->aux_rgb,
+                    &s->aux_id, &s->aux_t})
+    b->release();
+  delete s;
+}
+
+int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
+  if (!d || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (d->abi_version != RT_ABI_VERSION)
+    return fail(RT_ERR_INVALID_ARG, "rt_scene_desc.abi_version %u != %u", d->abi_version, RT_ABI_VERSION);
+  if (d->n_spheres && (!d->sphere_center || !d->sphere_r_sq || !d->sphere_material))
+    return fail(RT_ERR_INVALID_ARG, "sphere arrays missing");
+  if (d->n_triangles && (!d->tri_v1 || !d->tri_e1 || !d->tri_e2 || !d->tri_normal || !d->tri_material))
+    return fail(RT_ERR_INVALID_ARG, "triangle arrays missing");
+  if ((d->n_spheres || d->n_triangles) && (!d->n_materials || !d->materials))
+    return fail(RT_ERR_INVALID_ARG, "materials missing");
+  if (d->n_lights && !d->lights) return fail(RT_ERR_INVALID_ARG, "lights missing");
+  for (uint32_t i = 0; i < d->n_spheres; i++)
+    if (d->sphere_material[i] >= d->n_materials) return fail(RT_ERR_INVALID_ARG, "sphere %u: material out of range", i);
+  for (uint32_t i = 0; i < d->n_triangles; i++)
+    if (d->tri_material[i] >= d->n_materials) return fail(RT_ERR_INVALID_ARG, "triangle %u: material out of range", i);
+
+  int ndev = rt_device_count();
+  if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  rt_scene* s = new rt_scene();
+  s->device = device;
+  auto bail = [&](int rc) {
+    rt_scene_destroy(s);
+    return rc;
+  };
+  auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+    int rc = b.ensure(bytes);
+    if (rc != RT_OK) return rc;
+    if (bytes) {
+      hipError_t e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(RT_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    }
+    return RT_OK;
+  };
+
+  const uint32_t ns = d->n_spheres, nt = d->n_triangles;
+  int rc;
+  {
+    std::vector<float> sp(4 * (size_t)ns);
+    for (uint32_t i = 0; i < ns; i++) {
+      sp[4 * i + 0] = d->sphere_center[3 * i + 0];
+      sp[4 * i + 1] = d->sphere_center[3 * i + 1];
+      sp[4 * i + 2] = d->sphere_center[3 * i + 2];
+      sp[4 * i + 3] = d->sphere_r_sq[i];
+    }
+    if ((rc = upload(s->spheres, sp.data(), sp.size() * 4)) != RT_OK) return bail(rc);
+    if ((rc = upload(s->sphere_mat, d->sphere_material, (size_t)ns * 4)) != RT_OK) return bail(rc);
+  }
+  RtBvh bvh;
+  rt_build_bvh(d->tri_v1, d->tri_e1, d->tri_e2, nt, &bvh);
+  {
+    // leaf-order intersection records; shading records twice: [0,nt) leaf order, [nt,2nt) canonical
+    std::vector<float> isect(12 * (size_t)nt), shade(8 * (size_t)nt);
+    for (uint32_t slot = 0; slot < nt; slot++) {
+      uint32_t t = bvh.tri_order[slot];
+      const float* v1 = d->tri_v1 + 3 * (size_t)t;
+      const float* e1 = d->tri_e1 + 3 * (size_t)t;
+      const float* e2 = d->tri_e2 + 3 * (size_t)t;
+      // X = e1 x e2 in ultraviolet's cross form, bit-equal to cross(-e1, -e2) (triangle.rs:174-177).
+      // volatile keeps the host compiler from contracting mul+add into an fma.
+      volatile float a0 = e1[1] * e2[2], b0 = e1[2] * e2[1];
+      volatile float a1 = e1[2] * e2[0], b1 = e1[0] * e2[2];
+      volatile float a2 = e1[0] * e2[1], b2 = e1[1] * e2[0];
+      float X[3] = {a0 + (-b0), a1 + (-b1), a2 + (-b2)};
+      float* q = &isect[12 * (size_t)slot];
+      q[0] = v1[0], q[1] = v1[1], q[2] = v1[2], q[3] = e1[0];
+      q[4] = e1[1], q[5] = e1[2], q[6] = e2[0], q[7] = e2[1];
+      q[8] = e2[2], q[9] = X[0], q[10] = X[1], q[11] = X[2];
+      for (int pass = 0; pass < 2; pass++) {
+        size_t dst = pass == 0 ? (size_t)slot : (size_t)nt + t;
+        float* sh = &shade[4 * dst];
+        sh[0] = d->tri_normal[3 * (size_t)t + 0];
+        sh[1] = d->tri_normal[3 * (size_t)t + 1];
+        sh[2] = d->tri_normal[3 * (size_t)t + 2];
+        uint32_t m = d->tri_material[t];
+        memcpy(&sh[3], &m, 4);
+      }
+    }
+    if ((rc = upload(s->tri_isect, isect.data(), isect.size() * 4)) != RT_OK) return bail(rc);
+    if ((rc = upload(s->tri_shade, shade.data(), shade.size() * 4)) != RT_OK) return bail(rc);
+    if ((rc = upload(s->tri_id, bvh.tri_order.data(), (size_t)nt * 4)) != RT_OK) return bail(rc);
+    if ((rc = upload(s->nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
+  }
+  {
+    std::vector<float> m(12 * (size_t)d->n_materials, 0.f);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+      const float* r = d->materials + (size_t)i * RT_MATERIAL_STRIDE;
+      float* o = &m[12 * (size_t)i];
+      o[0] = r[RT_MAT_R], o[1] = r[RT_MAT_G], o[2] = r[RT_MAT_B], o[3] = r[RT_MAT_METALLIC];
+      o[4] = r[RT_MAT_SHININESS], o[5] = r[RT_MAT_IOR], o[6] = r[RT_MAT_OPACITY], o[7] = r[RT_MAT_BOOST];
+      o[8] = r[RT_MAT_HAS_OPACITY];
+    }
+    if ((rc = upload(s->materials, m.data(), m.size() * 4)) != RT_OK) return bail(rc);
+    std::vector<float> l(8 * (size_t)d->n_lights, 0.f);
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+      const float* r = d->lights + (size_t)i * RT_LIGHT_STRIDE;
+      float* o = &l[8 * (size_t)i];
+      o[0] = r[0], o[1] = r[1], o[2] = r[2], o[3] = r[6];
+      o[4] = r[3], o[5] = r[4], o[6] = r[5];
+    }
+    if ((rc = upload(s->lights, l.data(), l.size() * 4)) != RT_OK) return bail(rc);
+  }
+  if ((rc = s->counters.ensure(8 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
+
+  s->dev.spheres = (const float4*)s->spheres.p;
+  s->dev.sphere_mat = (const uint32_t*)s->sphere_mat.p;
+  s->dev.tri_isect = (const float4*)s->tri_isect.p;
+  s->dev.tri_shade = (const float4*)s->tri_shade.p;
+  s->dev.tri_id = (const uint32_t*)s->tri_id.p;
+  s->dev.materials = (const float4*)s->materials.p;
+  s->dev.lights = (const float4*)s->lights.p;
+  s->dev.nodes = (const RtNode*)s->nodes.p;
+  s->dev.n_spheres = ns;
+  s->dev.n_triangles = nt;
+  s->dev.n_lights = d->n_lights;
+  s->dev.n_nodes = (uint32_t)bvh.nodes.size();
+  s->info.n_nodes = (uint32_t)bvh.nodes.size();
+  s->info.n_leaves = bvh.n_leaves;
+  s->info.max_depth = bvh.max_depth;
+  s->info.max_leaf_size = bvh.max_leaf;
+  s->info.bytes_nodes = bvh.nodes.size() * sizeof(RtNode);
+  s->info.bytes_triangles = (size_t)nt * (48 + 2 * 16 + 4);
+  if (bvh.max_depth + 2 > 64) return bail(fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth));
+  *out = s;
+  return RT_OK;
+}
+
+int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
+  if (!s || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
+  *out = s->info;
+  return RT_OK;
+}
+
+static int validate_params(const rt_params* p) {
+  if (!p) return fail(RT_ERR_INVALID_ARG, "null params");
+  if (p->abi_version != RT_ABI_VERSION)
+    return fail(RT_ERR_INVALID_ARG, "rt_params.abi_version %u != %u", p->abi_version, RT_ABI_VERSION);
+  if (p->width == 0 || p->height == 0) return fail(RT_ERR_INVALID_ARG, "empty frame");
+  if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(RT_ERR_INVALID_ARG, "frame too large");
+  if (p->win_w && (p->win_x0 + (uint64_t)p->win_w > p->width || p->win_y0 + (uint64_t)p->win_h > p->height || !p->win_h))
+    return fail(RT_ERR_INVALID_ARG, "window outside the frame");
+  if ((p->flags & RT_FLAG_ANTI_ALIASING) && p->aa_rays > 0 && !p->aa_offsets)
+    return fail(RT_ERR_INVALID_ARG, "aa_offsets missing");
+  if (p->light_mult > 1 && (!p->cloud_sets || p->n_cloud_sets == 0))
+    return fail(RT_ERR_INVALID_ARG, "cloud_sets missing");
+  if (p->n_ranks > 1 && p->rank >= p->n_ranks) return fail(RT_ERR_INVALID_ARG, "rank out of range");
+  if (p->traversal > RT_TRAVERSAL_LINEAR) return fail(RT_ERR_INVALID_ARG, "unknown traversal mode");
+  if (p->max_depth_reflection > 64 || p->max_depth_refraction > 64)
+    return fail(RT_ERR_UNSUPPORTED, "recursion depth > 64");
+  return RT_OK;
+}
+
+// fills the device parameter block, uploading tables / sizing workspaces as needed
+static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, hipStream_t stream,
+                   RtDevParams* P) {
+  memset(P, 0, sizeof(*P));
+  P->width = p->width;
+  P->height = p->height;
+  memcpy(P->focus, p->focus, sizeof(P->focus));
+  P->fw = p->fw, P->fh = p->fh, P->fd = p->fd;
+  P->eps_distance = p->eps_distance;
+  P->air_ior = p->air_ior;
+  P->ambient = p->ambient;
+  P->flags = p->flags;
+  const bool aa = (p->flags & RT_FLAG_ANTI_ALIASING) && p->aa_rays > 0;
+  P->aa_rays = aa ? p->aa_rays : 0;
+  int rc;
+  if (aa) {
+    size_t n = (size_t)p->aa_rays * 2;
+    if (s->aa_host.size() != n || memcmp(s->aa_host.data(), p->aa_offsets, n * 4) != 0) {
+      if ((rc = s->aa.ensure(n * 4)) != RT_OK) return rc;
+      s->aa_host.assign(p->aa_offsets, p->aa_offsets + n);
+      HIP_TRY(hipMemcpyAsync(s->aa.p, s->aa_host.data(), n * 4, hipMemcpyHostToDevice, stream));
+    }
+    P->aa_offsets = (const float*)s->aa.p;
+  }
+  P->light_mult = p->light_mult < 1 ? 1 : p->light_mult;
+  P->cloud_seed = p->cloud_seed;
+  P->n_cloud_sets = p->n_cloud_sets;
+  if (P->light_mult > 1) {
+    size_t n = (size_t)p->n_cloud_sets * P->light_mult * 3;
+    if (s->cloud_host.size() != n || memcmp(s->cloud_host.data(), p->cloud_sets, n * 4) != 0) {
+      if ((rc = s->cloud.ensure(n * 4)) != RT_OK) return rc;
+      s->cloud_host.assign(p->cloud_sets, p->cloud_sets + n);
+      HIP_TRY(hipMemcpyAsync(s->cloud.p, s->cloud_host.data(), n * 4, hipMemcpyHostToDevice, stream));
+    }
+    P->cloud_sets = (const float*)s->cloud.p;
+  }
+  P->max_depth_reflection = p->max_depth_reflection;
+  P->max_depth_refraction = p->max_depth_refraction;
+  if (p->win_w) {
+    P->win_x0 = p->win_x0, P->win_y0 = p->win_y0, P->win_w = p->win_w, P->win_h = p->win_h;
+  } else {
+    P->win_x0 = P->win_y0 = 0;
+    P->win_w = p->width;
+    P->win_h = p->height;
+  }
+  P->tile_size = p->tile_size ? p->tile_size : 48u;
+  P->n_ranks = p->n_ranks;
+  P->rank = p->rank;
+  P->traversal = p->traversal;
+  P->argb = argb_dev;
+  if (aux_dev) {
+    P->aux_rgb = aux_dev->rgb;
+    P->aux_hit_id = aux_dev->hit_id;
+    P->aux_hit_t = aux_dev->hit_t;
+  }
+  P->counters = (unsigned long long*)s->counters.p;
+  HIP_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(unsigned long long), stream));
+
+  const bool secondary = (p->flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
+  uint32_t bx = (P->win_w + RT_BLOCK_W - 1) / RT_BLOCK_W, by = (P->win_h + RT_BLOCK_H - 1) / RT_BLOCK_H;
+  P->path_threads = bx * by * 256u;
+  if (secondary) {
+    uint32_t md = p->max_depth_reflection > p->max_depth_refraction ? p->max_depth_reflection : p->max_depth_refraction;
+    P->path_levels = md + 1;
+    size_t bytes = (size_t)P->path_levels * RT_PATH_FIELDS * 4 * P->path_threads;
+    if ((rc = s->path.ensure(bytes)) != RT_OK) return rc;
+    P->path_stack = (float*)s->path.p;
+  }
+  return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, void* hip_stream) {
+  if (!s || !argb_dev) return fail(RT_ERR_INVALID_ARG, "null argument");
+  int rc = validate_params(p);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  RtDevParams P;
+  if ((rc = prepare(s, p, argb_dev, aux_dev, (hipStream_t)hip_stream, &P)) != RT_OK) return rc;
+  hipError_t e = (hipError_t)rt_launch_render(s->dev, P, hip_stream);
+  if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
+  if (!s || !st) return fail(RT_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  unsigned long long c[8];
+  HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+  st->rays_primary = c[0];
+  st->rays_reflection = c[1];
+  st->rays_refraction = c[2];
+  st->rays_shadow = c[3];
+  st->pixels_written = c[4];
+  return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux, rt_stats* stats) {
+  if (!s || !argb) return fail(RT_ERR_INVALID_ARG, "null argument");
+  int rc = validate_params(p);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  auto t_begin = std::chrono::steady_clock::now();
+  const size_t npix = (size_t)p->width * p->height;
+  if ((rc = s->fb.ensure(npix * 4)) != RT_OK) return rc;
+  // the caller's fill survives on miss pixels (image_buffer.rs:27-37): start from its content
+  HIP_TRY(hipMemcpy(s->fb.p, argb, npix * 4, hipMemcpyHostToDevice));
+  rt_aux ad{};
+  if (aux) {
+    if (aux->rgb) {
+      if ((rc = s->aux_rgb.ensure(npix * 12)) != RT_OK) return rc;
+      HIP_TRY(hipMemcpy(s->aux_rgb.p, aux->rgb, npix * 12, hipMemcpyHostToDevice));
+      ad.rgb = (float*)s->aux_rgb.p;
+    }
+    if (aux->hit_id) {
+      if ((rc = s->aux_id.ensure(npix * 4)) != RT_OK) return rc;
+      HIP_TRY(hipMemcpy(s->aux_id.p, aux->hit_id, npix * 4, hipMemcpyHostToDevice));
+      ad.hit_id = (int32_t*)s->aux_id.p;
+    }
+    if (aux->hit_t) {
+      if ((rc = s->aux_t.ensure(npix * 4)) != RT_OK) return rc;
+      HIP_TRY(hipMemcpy(s->aux_t.p, aux->hit_t, npix * 4, hipMemcpyHostToDevice));
+      ad.hit_t = (float*)s->aux_t.p;
+    }
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  RtDevParams P;
+  if ((rc = prepare(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P)) != RT_OK) return rc;
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  hipError_t le = (hipError_t)rt_launch_render(s->dev, P, nullptr);
+  if (le != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+  HIP_TRY(hipEventRecord(e1, nullptr));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(hipMemcpy(argb, s->fb.p, npix * 4, hipMemcpyDeviceToHost));
+  if (aux) {
+    if (aux->rgb) HIP_TRY(hipMemcpy(aux->rgb, s->aux_rgb.p, npix * 12, hipMemcpyDeviceToHost));
+    if (aux->hit_id) HIP_TRY(hipMemcpy(aux->hit_id, s->aux_id.p, npix * 4, hipMemcpyDeviceToHost));
+    if (aux->hit_t) HIP_TRY(hipMemcpy(aux->hit_t, s->aux_t.p, npix * 4, hipMemcpyDeviceToHost));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    if ((rc = rt_render_collect_stats(s, stats)) != RT_OK) return rc;
+    stats->kernel_ms = ms;
+    stats->total_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return RT_OK;
+}
+
+}  // extern "C"

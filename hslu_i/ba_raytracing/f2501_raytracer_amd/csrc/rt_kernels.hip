@@ -1,0 +1,752 @@
+// rt_kernels.hip -- the per-pixel render loop as one hand-written gfx950 (CDNA4) kernel.
+//
+// Path implemented (reference file:line, all fp32):
+//   primary rays            src/renderer/raytracer_renderer.rs:1190-1357, src/renderer/mod.rs:146-209
+//   AA sample accumulation  raytracer_renderer.rs:918-1016 (sample table comes in through rt_params)
+//   nearest hit             src/raytracing/raytracer.rs:162-220
+//   shadow / transmittance  raytracer.rs:24-106
+//   sphere / triangle test  src/geometry/basic/sphere.rs:78-162, triangle.rs:149-212
+//   Whitted shading         raytracer_renderer.rs:147-264 (node), :731-874 (lighting),
+//                           :526-729 (reflection), :279-524 (refraction), :266-277 (attenuation)
+//   Fresnel / absorption    src/raytracing/material.rs:468-525, :213-231
+//   point light             src/scene/lighting/light.rs:261-299, cloud :183-225
+//   pixel pack              src/output/window.rs:105-109
+//
+// Execution model (MI355X-first, nothing like the reference's rayon + 8-lane packets):
+//   * one thread per pixel, one 64-lane wavefront per 8x8 pixel tile, 4 waves per workgroup
+//     (16x16 pixels), AA samples iterated inside the thread;
+//   * BVH traversal is WAVE-COOPERATIVE: the 64 rays of a wavefront walk the tree together.  The
+//     current node index is wave-uniform, so node and triangle records are fetched once per wave
+//     (uniform address -> scalar/broadcast loads) and the traversal stack is ONE stack per
+//     wavefront kept in LDS, driven by __ballot votes; lanes whose ray misses a box are masked
+//     for that subtree.  Coherent rays (camera rays of a tile, shadow rays of neighbouring hit
+//     points towards one light) make the union of visited nodes close to the per-ray set;
+//   * the Whitted recursion is an explicit per-thread ray stack in HBM (SoA, coalesced), each
+//     entry carrying its RGB path weight; contributions are linear in the child colour so the
+//     sum over the tree equals the recursion up to fp reassociation;
+//   * no MFMA: this is branchy fp32 intersection math, not a contraction.
+//
+// Numerics: compiled with -ffp-contract=off; fused multiply-adds appear exactly where the
+// reference calls mul_add (written __builtin_fmaf).  Division and sqrt are the correctly rounded
+// forms (hipcc default), so every hit/miss decision and every t is bit-identical to the CPU
+// restatement in oracle/; only tanhf/powf differ in the last ulps.
+#include <hip/hip_runtime.h>
+
+#include "rt_internal.h"
+
+#define RT_EPS 1.1920929e-7f
+#define RT_WAVES_PER_BLOCK 4
+#define RT_STACK_DEPTH 64
+
+namespace {
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) {
+  V3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator/(V3 a, V3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// ultraviolet Vec3::dot = x.mul_add(ox, y.mul_add(oy, z*oz))
+__device__ __forceinline__ float dot(V3 a, V3 b) {
+  return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z));
+}
+__device__ __forceinline__ float mag(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) {
+  float r = 1.0f / mag(a);
+  return a * r;
+}
+__device__ __forceinline__ V3 fma_s(V3 d, float t, V3 o) {
+  return mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z));
+}
+__device__ __forceinline__ V3 reflected(V3 v, V3 n) {
+  float k = 2.0f * dot(v, n);
+  return v - n * k;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+  return fminf(fmaxf(x, lo), hi);
+}
+__device__ __forceinline__ bool has_nan(V3 a) { return (a.x != a.x) | (a.y != a.y) | (a.z != a.z); }
+
+struct Mat {
+  V3 color;
+  float metallic, shininess, ior, opacity, boost;
+  bool transmissive;  // TransmissionProperties::mask, material.rs:44-50
+};
+
+__device__ __forceinline__ Mat load_mat(const RtDevScene& sc, uint32_t idx) {
+  const float4 a = sc.materials[3 * idx + 0];
+  const float4 b = sc.materials[3 * idx + 1];
+  const float4 c = sc.materials[3 * idx + 2];
+  Mat m;
+  m.color = mk(a.x, a.y, a.z);
+  m.metallic = a.w;
+  m.shininess = b.x;
+  m.ior = b.y;
+  m.opacity = b.z;
+  m.boost = b.w;
+  m.transmissive = (c.x != 0.0f) && !(fabsf(m.opacity - 0.0f) <= RT_EPS);
+  return m;
+}
+
+// Material::compute_fresnel (reflectance), material.rs:468-525
+__device__ __forceinline__ V3 fresnel_reflectance(const Mat& m, V3 normal, V3 view, float other_ior) {
+  if (!m.transmissive) return mk(m.metallic, m.metallic, m.metallic);
+  float ior = m.ior;
+  float n_dot_v = dot(normal, view);
+  float cos_theta = fabsf(n_dot_v);
+  bool inside = n_dot_v < 0.0f;
+  float eta_t = inside ? (ior / other_ior) : (other_ior / ior);
+  float sin2_t = eta_t * eta_t * (1.0f - cos_theta * cos_theta);
+  bool reflective = m.metallic > 0.0f;
+  bool tir = (inside && sin2_t > 1.0f) || reflective;
+  float q = (other_ior - ior) / (other_ior + ior);
+  float f0 = q * q;
+  float omt = 1.0f - m.metallic;
+  V3 f0v = mk(f0 * omt + m.color.x * m.metallic, f0 * omt + m.color.y * m.metallic,
+              f0 * omt + m.color.z * m.metallic);
+  float c1 = 1.0f - cos_theta;
+  float c2 = c1 * c1;
+  float c5 = c1 * (c2 * c2);
+  V3 fres = mk(f0v.x + (1.0f - f0v.x) * c5, f0v.y + (1.0f - f0v.y) * c5, f0v.z + (1.0f - f0v.z) * c5);
+  float ra = reflective ? m.metallic : 1.0f;
+  return tir ? mk(ra, ra, ra) : fres;
+}
+
+// Material::absorption, material.rs:213-231
+__device__ __forceinline__ V3 absorption(const Mat& m) {
+  float op = m.transmissive ? m.opacity : 1.0f;
+  op = clampf(op, 0.0f, 1.0f - RT_EPS);
+  return m.color * (1.0f - op);
+}
+
+// attenuation_factor_based_on_distance, raytracer_renderer.rs:266-277
+__device__ __forceinline__ float atten(float t) {
+  float d = fabsf(t);
+  float a = 1.0f / (1.0f + d + 0.1f * d * d);
+  return clampf(a, 0.0f, 1.0f);
+}
+
+// SphereData::intersect, sphere.rs:78-162.  `s` = {cx, cy, cz, r_sq} (wave-uniform).
+__device__ __forceinline__ bool sphere_hit(float4 s, V3 o, V3 d, float& t_out) {
+  V3 v = o - mk(s.x, s.y, s.z);
+  float b = 2.0f * dot(d, v);
+  float cc = dot(v, v) - s.w;
+  float disc = __builtin_fmaf(b, b, (2.0f * -2.0f) * cc);
+  if (!(disc >= 0.0f)) return false;
+  float sq = __builtin_sqrtf(disc);
+  float mba = (-b) * 0.5f;
+  float sa = sq * 0.5f;
+  float t0 = mba - sa;
+  float t1 = mba + sa;
+  bool t0v = t0 >= 0.0f, t1v = t1 >= 0.0f;
+  bool use0 = t0v && (!t1v || t0 < t1);
+  bool use1 = t1v && !use0;
+  t_out = use0 ? t0 : t1;
+  return use0 || use1;
+}
+
+// TriangleData::intersect, triangle.rs:149-212 with ultraviolet Mat3::inversed/determinant.
+// q0 = {v1.xyz, e1.x}, q1 = {e1.yz, e2.xy}, q2 = {e2.z, X.xyz} with X = e1 x e2 (host, bit-equal
+// to cross(-e1, -e2)).
+__device__ __forceinline__ bool tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& t_out) {
+  V3 v1 = mk(q0.x, q0.y, q0.z);
+  V3 c1 = mk(-q0.w, -q1.x, -q1.y);  // -e1
+  V3 c2 = mk(-q1.z, -q1.w, -q2.x);  // -e2
+  V3 x = mk(q2.y, q2.z, q2.w);
+  V3 b = v1 - o;
+  // y = c2 x c0, z = c0 x c1 (ultraviolet cross: (a.y*b.z) + (-a.z*b.y), ...)
+  V3 y = mk((c2.y * d.z) + (-c2.z * d.y), (c2.z * d.x) + (-c2.x * d.z), (c2.x * d.y) + (-c2.y * d.x));
+  V3 z = mk((d.y * c1.z) + (-d.z * c1.y), (d.z * c1.x) + (-d.x * c1.z), (d.x * c1.y) + (-d.y * c1.x));
+  float det_i = dot(d, x);
+  float inv_det = 1.0f / det_i;
+  V3 r0 = x * inv_det, r1 = y * inv_det, r2 = z * inv_det;
+  float t = r0.x * b.x + r0.y * b.y + r0.z * b.z;
+  float u = r1.x * b.x + r1.y * b.y + r1.z * b.z;
+  float v = r2.x * b.x + r2.y * b.y + r2.z * b.z;
+  float det = d.x * (c1.y * c2.z - c2.y * c1.z) - c1.x * (d.y * c2.z - c2.y * d.z) +
+              c2.x * (d.y * c1.z - c1.y * d.z);
+  bool t_invalid = t <= RT_EPS;
+  bool uv_invalid = (u < 0.0f) || (v < 0.0f) || ((u + v) >= 1.0f);
+  bool valid = !(t_invalid || uv_invalid) && !(fabsf(det - 0.0f) <= RT_EPS);
+  t_out = t;
+  return valid;
+}
+
+// conservative slab test against a padded box; NaN-safe through fminf/fmaxf
+__device__ __forceinline__ bool box_hit(const float* lo, const float* hi, V3 o, V3 inv, float tlimit,
+                                        float& tnear) {
+  float tx1 = (lo[0] - o.x) * inv.x, tx2 = (hi[0] - o.x) * inv.x;
+  float ty1 = (lo[1] - o.y) * inv.y, ty2 = (hi[1] - o.y) * inv.y;
+  float tz1 = (lo[2] - o.z) * inv.z, tz2 = (hi[2] - o.z) * inv.z;
+  float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+  float tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+  tnear = tmin;
+  // slack: a few ulps of the magnitudes involved, on top of the padded boxes
+  float slack = 1e-5f + 4e-6f * fabsf(tmax);
+  return (tmin <= tmax + slack) && (tmax >= -slack) && (tmin <= tlimit + slack + 4e-6f * fabsf(tlimit));
+}
+
+struct Hit {
+  float t;
+  int id;  // canonical object index, -1 = none
+};
+
+struct Shadow {
+  bool occluded;
+  float opacity;
+  V3 filter;
+};
+
+// one transmissive / opaque occluder on a shadow ray, raytracer.rs:53-92
+__device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n, V3 d) {
+  float io = 0.0f;
+  if (m.transmissive) {
+    V3 refl = fresnel_reflectance(m, n, -d, 1.0f);
+    io = m.opacity * (1.0f - refl.x);
+  }
+  S.opacity = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
+  if (!m.transmissive && fabsf(S.opacity - 0.0f) <= RT_EPS) S.occluded = true;
+  S.filter = S.filter - absorption(m);
+}
+
+struct WaveCtx {
+  uint32_t* stack;  // this wavefront's traversal stack in LDS
+};
+
+// ------------------------------------------------------------------------------------------------
+// nearest hit: spheres linearly (wave-uniform loop), triangles through the BVH or linearly
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
+                                           bool alive, V3 o, V3 d) {
+  Hit best;
+  best.t = INFINITY;
+  best.id = -1;
+  for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    float4 s = sc.spheres[i];
+    float t;
+    bool h = alive && sphere_hit(s, o, d, t);
+    if (CULL && h) {  // sphere.rs:137-151
+      V3 p = fma_s(d, t, o);
+      V3 n = normalize(p - mk(s.x, s.y, s.z));
+      Mat m = load_mat(sc, sc.sphere_mat[i]);
+      h = (dot(d, n) < 0.75f) || m.transmissive;
+    }
+    if (h && t <= best.t) {
+      best.t = t;
+      best.id = (int)i;
+    }
+  }
+  if (sc.n_triangles == 0) return best;
+  const int tri_base = (int)sc.n_spheres;
+
+  auto test_tri = [&](uint32_t slot, bool lane_on) {
+    float4 q0 = sc.tri_isect[3 * slot + 0];
+    float4 q1 = sc.tri_isect[3 * slot + 1];
+    float4 q2 = sc.tri_isect[3 * slot + 2];
+    float t;
+    bool h = lane_on && tri_hit(q0, q1, q2, o, d, t);
+    if (CULL) {  // triangle.rs:154-168
+      if (__ballot(h)) {
+        float4 sh = sc.tri_shade[slot];
+        Mat m = load_mat(sc, __float_as_uint(sh.w));
+        h = h && ((dot(d, mk(sh.x, sh.y, sh.z)) < 0.75f) || m.transmissive);
+      }
+    }
+    if (__ballot(h)) {
+      int id = tri_base + (int)sc.tri_id[slot];
+      if (h && (t < best.t || (t == best.t && id > best.id))) {
+        best.t = t;
+        best.id = id;
+      }
+    }
+  };
+
+  if (P.traversal == RT_TRAVERSAL_LINEAR) {
+    for (uint32_t s = 0; s < sc.n_triangles; s++) test_tri(s, alive);
+    return best;
+  }
+
+  V3 inv = mk(__frcp_rn(d.x), __frcp_rn(d.y), __frcp_rn(d.z));
+  uint32_t sp = 0;
+  uint32_t node = 0;
+  for (;;) {
+    const RtNode nd = sc.nodes[node];
+    float tn0, tn1;
+    bool h0 = alive && box_hit(nd.lo0, nd.hi0, o, inv, best.t, tn0);
+    bool h1 = alive && box_hit(nd.lo1, nd.hi1, o, inv, best.t, tn1);
+    unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+    uint32_t next = RT_NODE_EMPTY;
+    bool in0 = false, in1 = false;  // internal children to descend into
+    if (b0) {
+      if (nd.n0) {
+        for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
+      } else {
+        in0 = true;
+      }
+    }
+    if (b1) {
+      if (nd.n1) {
+        for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
+      } else {
+        in1 = true;
+      }
+    }
+    if (in0 && in1) {
+      // near-first by wave vote among lanes that hit both children
+      unsigned long long both = b0 & b1;
+      unsigned long long pref1 = __ballot(h0 && h1 && (tn1 < tn0));
+      bool first1 = 2 * __popcll(pref1) > __popcll(both);
+      uint32_t nearc = first1 ? nd.c1 : nd.c0;
+      uint32_t farc = first1 ? nd.c0 : nd.c1;
+      W.stack[sp] = farc;
+      sp++;
+      next = nearc;
+    } else if (in0) {
+      next = nd.c0;
+    } else if (in1) {
+      next = nd.c1;
+    }
+    if (next == RT_NODE_EMPTY) {
+      if (sp == 0) break;
+      sp--;
+      next = W.stack[sp];
+    }
+    node = __builtin_amdgcn_readfirstlane(next);
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shadow / transmittance ray: every hit <= tmax counts (raytracer.rs:24-106); a lane stops as soon
+// as it is completely occluded (its result is discarded by the caller, :800-802)
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
+                                             bool alive, V3 o, V3 d_raw, float tmax) {
+  Shadow S;
+  S.occluded = false;
+  S.opacity = 1.0f;
+  S.filter = mk(1.0f, 1.0f, 1.0f);
+  V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
+  for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    float4 s = sc.spheres[i];
+    float t;
+    bool h = alive && !S.occluded && sphere_hit(s, o, d, t);
+    h = h && (t <= tmax);
+    if (__ballot(h)) {
+      if (h) {
+        V3 p = fma_s(d, t, o);
+        V3 n = normalize(p - mk(s.x, s.y, s.z));
+        Mat m = load_mat(sc, sc.sphere_mat[i]);
+        bool vis = true;
+        if (CULL) vis = (dot(d, n) < 0.75f) || m.transmissive;
+        if (vis) shadow_accumulate(S, m, n, d);
+      }
+    }
+  }
+  if (sc.n_triangles == 0) return S;
+
+  auto test_tri = [&](uint32_t slot, bool lane_on) {
+    float4 q0 = sc.tri_isect[3 * slot + 0];
+    float4 q1 = sc.tri_isect[3 * slot + 1];
+    float4 q2 = sc.tri_isect[3 * slot + 2];
+    float t;
+    bool h = lane_on && !S.occluded && tri_hit(q0, q1, q2, o, d, t);
+    h = h && (t <= tmax);
+    if (__ballot(h)) {
+      float4 sh = sc.tri_shade[slot];
+      Mat m = load_mat(sc, __float_as_uint(sh.w));
+      V3 n = mk(sh.x, sh.y, sh.z);
+      if (CULL) h = h && ((dot(d, n) < 0.75f) || m.transmissive);
+      if (h) shadow_accumulate(S, m, n, d);
+    }
+  };
+
+  if (P.traversal == RT_TRAVERSAL_LINEAR) {
+    for (uint32_t s = 0; s < sc.n_triangles; s++) test_tri(s, alive);
+    return S;
+  }
+
+  V3 inv = mk(__frcp_rn(d.x), __frcp_rn(d.y), __frcp_rn(d.z));
+  uint32_t sp = 0;
+  uint32_t node = 0;
+  for (;;) {
+    const RtNode nd = sc.nodes[node];
+    float tn0, tn1;
+    bool live = alive && !S.occluded;
+    if (!__ballot(live)) break;
+    bool h0 = live && box_hit(nd.lo0, nd.hi0, o, inv, tmax, tn0);
+    bool h1 = live && box_hit(nd.lo1, nd.hi1, o, inv, tmax, tn1);
+    unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+    uint32_t next = RT_NODE_EMPTY;
+    bool in0 = false, in1 = false;
+    if (b0) {
+      if (nd.n0) {
+        for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
+      } else {
+        in0 = true;
+      }
+    }
+    if (b1) {
+      if (nd.n1) {
+        for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
+      } else {
+        in1 = true;
+      }
+    }
+    if (in0 && in1) {
+      W.stack[sp] = nd.c1;
+      sp++;
+      next = nd.c0;
+    } else if (in0) {
+      next = nd.c0;
+    } else if (in1) {
+      next = nd.c1;
+    }
+    if (next == RT_NODE_EMPTY) {
+      if (sp == 0) break;
+      sp--;
+      next = W.stack[sp];
+    }
+    node = __builtin_amdgcn_readfirstlane(next);
+  }
+  return S;
+}
+
+// surface data of a hit (SurfaceInteraction, surface_interaction.rs)
+struct Surf {
+  V3 p, n;
+  uint32_t mat;
+};
+__device__ __forceinline__ Surf surface_of(const RtDevScene& sc, Hit h, V3 o, V3 d) {
+  Surf s;
+  s.p = fma_s(d, h.t, o);
+  if (h.id < (int)sc.n_spheres) {
+    float4 sp = sc.spheres[h.id];
+    s.n = normalize(s.p - mk(sp.x, sp.y, sp.z));
+    s.mat = sc.sphere_mat[h.id];
+  } else {
+    // tri_shade is stored in canonical order for this lookup (see rt_api.cpp)
+    float4 sh = sc.tri_shade[sc.n_triangles + (uint32_t)(h.id - (int)sc.n_spheres)];
+    s.n = mk(sh.x, sh.y, sh.z);
+    s.mat = __float_as_uint(sh.w);
+  }
+  return s;
+}
+
+__device__ __forceinline__ uint32_t to_u8(float x) {
+  float cx = fminf(fmaxf(x, 0.0f), 1.0f);
+  return (uint32_t)__float2uint_rn(cx * 255.0f);
+}
+
+enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
+
+template <bool CULL>
+__device__ __forceinline__ void render_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  WaveCtx W;
+  W.stack = lds_stack + wave * RT_STACK_DEPTH;
+
+  // 16x16 pixel block, each wave an 8x8 tile
+  const uint32_t blocks_x = (P.win_w + RT_BLOCK_W - 1) / RT_BLOCK_W;
+  const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+  const uint32_t lx = bx * RT_BLOCK_W + (wave & 1u) * 8u + (lane & 7u);
+  const uint32_t ly = by * RT_BLOCK_H + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
+  bool pix_on = (lx < P.win_w) && (ly < P.win_h);
+  if (pix_on && P.n_ranks > 1) {
+    uint32_t tiles_x = (P.width + P.tile_size - 1) / P.tile_size;
+    uint32_t tile = (gy / P.tile_size) * tiles_x + (gx / P.tile_size);
+    pix_on = (rt_tile_perm(tile) % P.n_ranks) == P.rank;
+  }
+  if (!__ballot(pix_on)) return;  // wave-uniform exit; no block-level barrier is used below
+
+  const uint32_t pix = gy * P.width + gx;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const float x = (float)gx * P.fw;  // renderer/mod.rs:176-180
+  const float y = (float)gy * P.fh;
+  const V3 coords = mk(x, y, 0.0f);
+  const V3 D = coords - mk(P.focus[0], P.focus[1], P.focus[2]);
+  const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
+  const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
+  const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
+  const uint32_t n_samples = aa ? P.aa_rays : 1u;
+  const float scale = aa ? 1.0f / (float)(((n_samples + 7u) / 8u) * 8u) : 1.0f;
+  const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0 && P.path_levels > 0;
+
+  unsigned long long cnt_primary = 0, cnt_refl = 0, cnt_refr = 0, cnt_shadow = 0;
+  V3 pixel = mk(0.0f, 0.0f, 0.0f);
+  bool any_hit = false;
+  int id0 = -1;
+  float t0 = 0.0f;
+
+  for (uint32_t k = 0; k < n_samples; k++) {
+    // current ray of this lane
+    V3 o = coords, d_raw = D;
+    if (aa) {
+      o.x = coords.x + P.aa_offsets[2 * k];
+      o.y = coords.y + P.aa_offsets[2 * k + 1];
+    }
+    float n_start = P.air_ior;
+    int depth = -1;  // Option<usize>::None
+    int kind = KIND_PRIMARY;
+    V3 Wt = mk(scale, scale, scale);  // path weight
+    bool have = pix_on;
+    uint32_t level = 0;  // entries on this lane's path stack
+
+    // iterate the Whitted tree: wave loops while any lane still has a ray
+    while (__ballot(have)) {
+      V3 d = normalize(d_raw);  // Ray::new_with_mask, ray.rs:52-57
+      bool alive = have && !has_nan(d);
+      // ray accounting: lanes entering cast_ray, by kind (kinds differ per lane once trees diverge)
+      cnt_primary += (unsigned long long)__popcll(__ballot(alive && kind == KIND_PRIMARY));
+      cnt_refl += (unsigned long long)__popcll(__ballot(alive && kind == KIND_REFL));
+      cnt_refr += (unsigned long long)__popcll(__ballot(alive && kind == KIND_REFR));
+
+      Hit h = nearest_hit<CULL>(sc, P, W, alive, o, d);
+      bool hit = alive && h.id >= 0;
+      if (kind == KIND_PRIMARY && have) {
+        if (hit) any_hit = true;
+        if (k == 0) {
+          id0 = hit ? h.id : -1;
+          t0 = h.t;
+        }
+      }
+
+      bool spawn_refl = false, spawn_refr = false;
+      V3 refl_o, refl_d, refl_W, refr_o, refr_d, refr_W;
+      float refr_ior = 0.0f;
+      int refl_depth = 0, refr_depth = 0;
+
+      if (__ballot(hit)) {
+        Surf sf;
+        Mat m;
+        sf.p = mk(0, 0, 0);
+        sf.n = mk(0, 0, 1);
+        sf.mat = 0;
+        if (hit) sf = surface_of(sc, h, o, d);
+        m = load_mat(sc, sf.mat);
+        // a reflection child's weight carries atten(child.t), known only now (:722-726)
+        float a = atten(h.t);
+        if (kind == KIND_REFL) Wt = Wt * a;
+
+        // ---- calculate_lighting, raytracer_renderer.rs:731-874 ------------------------------
+        V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
+        const bool has_spec = m.shininess > 0.0f;
+        for (uint32_t l = 0; l < sc.n_lights; l++) {
+          const float4 L0 = sc.lights[2 * l + 0];
+          const float4 L1 = sc.lights[2 * l + 1];
+          const V3 lc = mk(L1.x, L1.y, L1.z);
+          const float* cs = nullptr;
+          float lI = L0.w;
+          if (N > 1) {
+            uint32_t set = rt_cloud_hash(P.cloud_seed, pix, l) % P.n_cloud_sets;
+            cs = P.cloud_sets + (size_t)set * N * 3u;
+            lI = (1.0f / (float)N) * L0.w;
+          }
+          for (uint32_t j = 0; j < N; j++) {
+            V3 lp = mk(L0.x, L0.y, L0.z);
+            if (N > 1 && hit) {
+              lp.x = L0.x + cs[3 * j + 0] * P.fw;  // light.rs:218
+              lp.y = L0.y + cs[3 * j + 1] * P.fh;
+              lp.z = L0.z + cs[3 * j + 2] * P.fd;
+            }
+            V3 ltp = lp - sf.p;
+            V3 ld = normalize(ltp);
+            V3 so = sf.p + ld * epsv;
+            float tmax = mag(lp - so);
+            cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
+            Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax);
+            bool reach = hit && !S.occluded;
+            if (!__ballot(reach)) continue;
+            // PointLight::calculate_contribution_at, light.rs:261-299
+            float dist = mag(ltp) + RT_EPS;
+            float cosi = dot(ltp, sf.n) / dist;
+            bool pos = cosi > 0.0f;
+            float att = 0.95f * (RT_EPS + dist + dist * dist);
+            float sig = (tanhf(att) + 1.0f) / 2.0f;
+            float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
+            V3 ccol = pos ? (m.color * lc) : mk(0, 0, 0);
+            float cint = pos ? lf : 0.0f;
+            V3 Lc = ccol / S.filter;
+            float diff = fmaxf(dot(sf.n, ld), 0.0f);
+            float specf = 0.0f;
+            if (has_spec) {
+              V3 rr = normalize(reflected(ld, sf.n));
+              float base = fmaxf(dot(rr, d), 0.0f);
+              specf = powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
+            }
+            float light_factor = diff * cint * S.opacity;
+            float spec_factor = cint * S.opacity * specf;
+            if (reach && diff > 0.0f) {
+              light_color = light_color + (m.color * Lc) * light_factor;
+              if (has_spec) spec_color = spec_color + lc * spec_factor;
+            }
+          }
+        }
+        V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
+        V3 direct = (ambient + light_color) * a;  // :206-209
+        V3 spec = spec_color * a;
+
+        if (hit) {
+          // own terms of this node (:251-257): transmissive ? spec : direct + spec
+          V3 own = m.transmissive ? spec : (direct + spec);
+          pixel = pixel + Wt * own;
+
+          const bool T = m.transmissive;
+          const bool R = (m.metallic > 0.0f) || T;
+          // ---- calculate_reflection, :526-729 ------------------------------------------------
+          if ((P.flags & RT_FLAG_REFLECTIONS) && R && secondary) {
+            float cos_theta = dot(d, sf.n);
+            bool inside = cos_theta < 0.0f;
+            V3 inormal = inside ? -sf.n : sf.n;
+            float n2 = inside ? m.ior : P.air_ior;
+            float eta = inside ? (n2 / n_start) : (n_start / n2);
+            float cos_i = fabsf(cos_theta);
+            float sin2 = eta * eta * (1.0f - cos_i * cos_i);
+            bool tir = sin2 >= 1.0f;
+            bool reflective = (m.metallic > 0.0f) || (T && tir);
+            int cd = depth < 0 ? (int)P.max_depth_reflection : (depth > 0 ? depth - 1 : 0);
+            if (reflective && cd > 0) {
+              V3 r = normalize(reflected(d, sf.n));
+              V3 Rf = fresnel_reflectance(m, inormal, -d, n_start);
+              spawn_refl = true;
+              refl_o = sf.p + r * epsv;
+              refl_d = r;
+              refl_W = Wt * Rf;
+              refl_depth = cd;
+            }
+          }
+          // ---- calculate_refractions, :279-524 -----------------------------------------------
+          if ((P.flags & RT_FLAG_REFRACTIONS) && T && secondary) {
+            float cos_theta = dot(d, sf.n);
+            bool inside = cos_theta <= 0.0f;
+            V3 inormal = inside ? -sf.n : sf.n;
+            float n2 = inside ? m.ior : P.air_ior;
+            float eta = inside ? (n2 / n_start) : (n_start / n2);
+            float inv_eta = 1.0f / eta;
+            V3 Rf = fresnel_reflectance(m, inormal, d, inv_eta);
+            V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
+            // ultraviolet refracted(n = -inormal, eta = 1/eta)
+            V3 nn = -inormal;
+            float ndi = dot(nn, d);
+            float kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
+            float op = m.opacity;
+            int step = (op < 0.5f) ? 2 : 1;
+            int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
+            int cd = depth < 0 ? (int)P.max_depth_refraction / fac : (depth > step ? depth - step : 0);
+            if (!(kk < 0.0f) && cd > 0) {  // kk < 0: zero vector -> NaN direction -> miss (D2)
+              float s = inv_eta * ndi + __builtin_sqrtf(kk);
+              V3 q = normalize(d * inv_eta - nn * s);
+              spawn_refr = true;
+              refr_o = sf.p + q * epsv;
+              refr_d = q;
+              refr_W = (Wt * (m.boost + 1.0f)) * Tr;
+              refr_ior = n2;
+              refr_depth = cd;
+            }
+          }
+        }
+      }
+
+      // ---- next ray of this lane: child, or pop, or done --------------------------------------
+      if (have) {
+        if (spawn_refl && spawn_refr) {
+          // push the refraction child, continue with the reflection child
+          float* ps = P.path_stack + (size_t)level * RT_PATH_FIELDS * P.path_threads + tid;
+          const size_t st = P.path_threads;
+          ps[0 * st] = refr_o.x;
+          ps[1 * st] = refr_o.y;
+          ps[2 * st] = refr_o.z;
+          ps[3 * st] = refr_d.x;
+          ps[4 * st] = refr_d.y;
+          ps[5 * st] = refr_d.z;
+          ps[6 * st] = refr_ior;
+          ps[7 * st] = refr_W.x;
+          ps[8 * st] = refr_W.y;
+          ps[9 * st] = refr_W.z;
+          ps[10 * st] = __int_as_float(refr_depth);
+          ps[11 * st] = __int_as_float(KIND_REFR);
+          level++;
+        }
+        if (spawn_refl) {
+          o = refl_o;
+          d_raw = refl_d;
+          Wt = refl_W;
+          depth = refl_depth;
+          kind = KIND_REFL;
+        } else if (spawn_refr) {
+          o = refr_o;
+          d_raw = refr_d;
+          Wt = refr_W;
+          n_start = refr_ior;
+          depth = refr_depth;
+          kind = KIND_REFR;
+        } else if (level > 0) {
+          level--;
+          const float* ps = P.path_stack + (size_t)level * RT_PATH_FIELDS * P.path_threads + tid;
+          const size_t st = P.path_threads;
+          o = mk(ps[0 * st], ps[1 * st], ps[2 * st]);
+          d_raw = mk(ps[3 * st], ps[4 * st], ps[5 * st]);
+          n_start = ps[6 * st];
+          Wt = mk(ps[7 * st], ps[8 * st], ps[9 * st]);
+          depth = __float_as_int(ps[10 * st]);
+          kind = __float_as_int(ps[11 * st]);
+        } else {
+          have = false;
+        }
+      }
+    }
+  }
+
+  if (pix_on) {
+    if (P.aux_hit_id) P.aux_hit_id[pix] = id0;
+    if (P.aux_hit_t && id0 >= 0) P.aux_hit_t[pix] = t0;
+    if (any_hit) {
+      P.argb[pix] = 0xFF000000u | (to_u8(pixel.x) << 16) | (to_u8(pixel.y) << 8) | to_u8(pixel.z);
+      if (P.aux_rgb) {
+        P.aux_rgb[3 * (size_t)pix + 0] = pixel.x;
+        P.aux_rgb[3 * (size_t)pix + 1] = pixel.y;
+        P.aux_rgb[3 * (size_t)pix + 2] = pixel.z;
+      }
+    }
+  }
+  unsigned long long written = (unsigned long long)__popcll(__ballot(pix_on && any_hit));
+  if (lane == 0 && P.counters) {
+    atomicAdd(&P.counters[0], cnt_primary);
+    atomicAdd(&P.counters[1], cnt_refl);
+    atomicAdd(&P.counters[2], cnt_refr);
+    atomicAdd(&P.counters[3], cnt_shadow);
+    atomicAdd(&P.counters[4], written);
+  }
+}
+
+__global__ __launch_bounds__(256) void rt_render_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ uint32_t lds_stack[RT_WAVES_PER_BLOCK * RT_STACK_DEPTH];
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    render_body<true>(sc, P, lds_stack);
+  else
+    render_body<false>(sc, P, lds_stack);
+}
+
+}  // namespace
+
+int rt_launch_render(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+  uint32_t bx = (p.win_w + RT_BLOCK_W - 1) / RT_BLOCK_W;
+  uint32_t by = (p.win_h + RT_BLOCK_H - 1) / RT_BLOCK_H;
+  dim3 grid(bx * by), block(256);
+  hipLaunchKernelGGL(rt_render_kernel, grid, block, 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}

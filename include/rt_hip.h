@@ -1,0 +1,236 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X-native render loop (drop-in for the reference's
+ * `Renderer::render` path).
+ *
+ * This is the boundary a Rust `impl Renderer<W,H,C> for HipRenderer` (or any other FFI host)
+ * binds.  Plain pointers and sizes only; no C++/torch types cross it.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *
+ *   rt_scene_create   <- Scene<Vec3>{scene_objects, scene_lights}      src/scene/scene.rs:24-27
+ *                        (flattened: spheres src/geometry/basic/sphere.rs:20-30,
+ *                         triangles src/geometry/basic/triangle.rs:22-48,
+ *                         materials src/raytracing/material.rs:15-19,78-89,
+ *                         point lights src/scene/lighting/light.rs:162-169)
+ *   rt_render         <- <RaytracerRenderer<C> as Renderer<W,H,C>>::render
+ *                        src/renderer/raytracer_renderer.rs:1360-1378, driver
+ *                        src/renderer/mod.rs:146-209; output layout = ImageBuffer<W,H>
+ *                        src/image_buffer.rs:8-15 packed by OutputColorEncoder::to_output
+ *                        src/output/window.rs:105-109
+ *   rt_render_device  <- same, but the packed pixels stay in a caller-provided DEVICE buffer
+ *                        (used by the multi-GPU gather and by bench.py, HBM-resident I/O)
+ *   rt_params         <- the compile-time feature/const table: src/lib.rs:30-92,
+ *                        src/renderer/raytracer_renderer.rs:55-127
+ *   rt_scene_destroy  <- Drop of Scene
+ *   rt_last_error     <- (reference panics: `unwrap()/expect()`); here: error codes + message
+ *
+ * All arithmetic on the path is fp32.  Hit ids are canonical object indices: spheres first
+ * (insertion order), then triangles (insertion order); -1 = miss.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* ---- error codes -------------------------------------------------------------------------- */
+#define RT_OK 0
+#define RT_ERR_INVALID_ARG (-1)
+#define RT_ERR_NO_DEVICE (-2)
+#define RT_ERR_HIP (-3)
+#define RT_ERR_OOM (-4)
+#define RT_ERR_UNSUPPORTED (-5)
+
+/* ---- feature flags (reference: Cargo features read through cfg!()) ------------------------ */
+#define RT_FLAG_REFLECTIONS 0x1u      /* feature "reflections"      raytracer_renderer.rs:216 */
+#define RT_FLAG_REFRACTIONS 0x2u      /* feature "refractions"      raytracer_renderer.rs:232 */
+#define RT_FLAG_BACKFACE_CULLING 0x4u /* feature "backface_culling" sphere.rs:137, triangle.rs:154 */
+#define RT_FLAG_ANTI_ALIASING 0x8u    /* feature "anti_aliasing"    raytracer_renderer.rs:1199 */
+
+/* ---- traversal selector (no reference counterpart: the reference scans linearly) ---------- */
+#define RT_TRAVERSAL_BVH 0u    /* BVH over the triangles (result-preserving w.r.t. the scan) */
+#define RT_TRAVERSAL_LINEAR 1u /* literal linear scan of all objects, raytracer.rs:48,180 */
+
+/* material row layout inside rt_scene_desc.materials (stride RT_MATERIAL_STRIDE floats) */
+#define RT_MATERIAL_STRIDE 9u
+#define RT_MAT_R 0
+#define RT_MAT_G 1
+#define RT_MAT_B 2
+#define RT_MAT_METALLIC 3
+#define RT_MAT_SHININESS 4
+#define RT_MAT_IOR 5         /* TransmissionProperties.refraction_index (raw field) */
+#define RT_MAT_OPACITY 6     /* TransmissionProperties.opacity value */
+#define RT_MAT_BOOST 7       /* TransmissionProperties.boost */
+#define RT_MAT_HAS_OPACITY 8 /* SimdOption mask of opacity: 1.0f = Some, 0.0f = None */
+
+/* light row layout inside rt_scene_desc.lights (stride RT_LIGHT_STRIDE floats).  The colour is
+ * the one PointLight::new stores, i.e. ALREADY passed through maximize_value (light.rs:175-181). */
+#define RT_LIGHT_STRIDE 7u
+
+typedef struct rt_scene_desc {
+  uint32_t abi_version; /* RT_ABI_VERSION */
+
+  uint32_t n_spheres;
+  const float* sphere_center;      /* [n_spheres][3] */
+  const float* sphere_r_sq;        /* [n_spheres]  radius*radius   sphere.rs:43 */
+  const float* sphere_r_inv;       /* [n_spheres]  1/radius        sphere.rs:44 (unused by intersect) */
+  const uint32_t* sphere_material; /* [n_spheres]  row in materials */
+
+  uint32_t n_triangles;
+  const float* tri_v1;          /* [n_triangles][3] vertex1           triangle.rs:35 */
+  const float* tri_e1;          /* [n_triangles][3] vertex2 - vertex1 triangle.rs:65,89 */
+  const float* tri_e2;          /* [n_triangles][3] vertex3 - vertex1 triangle.rs:66,90 */
+  const float* tri_normal;      /* [n_triangles][3] stored face normal (may be non-unit) */
+  const uint32_t* tri_material; /* [n_triangles] */
+
+  uint32_t n_materials;
+  const float* materials; /* [n_materials][RT_MATERIAL_STRIDE] */
+
+  uint32_t n_lights;
+  const float* lights; /* [n_lights][RT_LIGHT_STRIDE]: x,y,z, r,g,b, intensity */
+} rt_scene_desc;
+
+typedef struct rt_params {
+  uint32_t abi_version; /* RT_ABI_VERSION */
+  uint32_t width;       /* WINDOW_WIDTH  lib.rs:50 */
+  uint32_t height;      /* WINDOW_HEIGHT lib.rs:61 */
+
+  float focus[3];     /* RENDER_RAY_FOCUS lib.rs:88-89 */
+  float fw;           /* WINDOW_TO_SCENE_WIDTH_FACTOR  lib.rs:81 */
+  float fh;           /* WINDOW_TO_SCENE_HEIGHT_FACTOR lib.rs:82 */
+  float fd;           /* WINDOW_TO_SCENE_DEPTH_FACTOR  lib.rs:83 */
+  float eps_distance; /* Vector3DOperations::default_epsilon_distance vector.rs:697-700 */
+  float air_ior;      /* DEFAULT_REFRACTION_INDEX lib.rs:92 */
+  float ambient;      /* ambient intensity 0.08, raytracer_renderer.rs:754 */
+
+  uint32_t flags; /* RT_FLAG_* */
+
+  /* anti-aliasing sample table, already scaled and direction-multiplied
+   * (bundle_rays_for_simd_antialiased_raytracing, raytracer_renderer.rs:1021-1138):
+   * sample k origin = (x + aa_offsets[2k], y + aa_offsets[2k+1], 0).  Ignored (one centre ray)
+   * unless RT_FLAG_ANTI_ALIASING is set. */
+  uint32_t aa_rays;
+  const float* aa_offsets; /* [aa_rays][2] */
+
+  /* soft-shadow light cloud (PointLight::to_point_light_cloud<N>, light.rs:183-225).
+   * light_mult = N.  N == 1: the light itself.  N > 1: light j of the cloud of light l at pixel
+   * p sits at  pos_l + cloud_sets[set][j] * (fw, fh, fd)  with intensity (1/N)*I_l, where
+   * set = rt_cloud_hash(cloud_seed, p, l) % n_cloud_sets  -- the seeded, reproducible stand-in
+   * for the reference's unseeded per-pixel Poisson3D set. */
+  uint32_t light_mult;
+  uint32_t cloud_seed;
+  uint32_t n_cloud_sets;
+  const float* cloud_sets; /* [n_cloud_sets][light_mult][3], in "pixel units" */
+
+  uint32_t max_depth_reflection; /* RAYTRACE_REFLECTION_MAX_DEPTH raytracer_renderer.rs:55 */
+  uint32_t max_depth_refraction; /* RAYTRACE_REFRACTION_MAX_DEPTH raytracer_renderer.rs:65 */
+
+  /* sub-rectangle to render (ChunkView, image_buffer.rs:178-251).  win_w == 0 -> full frame. */
+  uint32_t win_x0, win_y0, win_w, win_h;
+
+  /* tile ownership for multi-GPU: RENDER_STRIDE x RENDER_STRIDE tiles (renderer/mod.rs:84-90,
+   * image_buffer.rs:48-97); this call renders the tiles t with  perm(t) % n_ranks == rank.
+   * n_ranks <= 1 -> all tiles. */
+  uint32_t tile_size; /* 0 -> 48 */
+  uint32_t n_ranks;
+  uint32_t rank;
+
+  uint32_t traversal; /* RT_TRAVERSAL_* */
+} rt_params;
+
+/* optional per-pixel debug planes for parity checks (all nullable, caller-owned, W*H each) */
+typedef struct rt_aux {
+  float* rgb;      /* [H*W][3] un-quantised linear RGB of written pixels (else untouched) */
+  int32_t* hit_id; /* [H*W] canonical object index hit by the first sample's primary ray, -1 miss */
+  float* hit_t;    /* [H*W] its distance (untouched on miss) */
+} rt_aux;
+
+typedef struct rt_stats {
+  uint64_t rays_primary;    /* lanes entering cast_ray as camera rays  raytracer.rs:162 */
+  uint64_t rays_reflection; /* ... as reflection children (raytracer_renderer.rs:698) */
+  uint64_t rays_refraction; /* ... as refraction children (raytracer_renderer.rs:493) */
+  uint64_t rays_shadow;     /* has_any_intersection calls, raytracer.rs:24 */
+  uint64_t pixels_written;
+  double kernel_ms; /* device time of the render kernel(s) (CPU oracle: wall time) */
+  double total_ms;  /* wall time of the call incl. copies */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */
+
+/* the two ABI-spec hashes below are also called from the HIP kernels */
+#if defined(__HIPCC__)
+#define RT_HOSTDEV __host__ __device__
+#else
+#define RT_HOSTDEV
+#endif
+
+/* deterministic hash that selects the per-(pixel, light) cloud set; part of the ABI spec */
+RT_HOSTDEV static inline uint32_t rt_cloud_hash(uint32_t seed, uint32_t pixel, uint32_t light) {
+  uint32_t h = seed * 0x9E3779B1u;
+  h ^= (pixel + 0x7F4A7C15u) * 0x85EBCA6Bu;
+  h ^= (light + 0x165667B1u) * 0xC2B2AE35u;
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
+}
+
+/* tile -> owner permutation for multi-GPU interleaving; part of the ABI spec */
+RT_HOSTDEV static inline uint32_t rt_tile_perm(uint32_t tile) {
+  uint32_t h = tile * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  return h;
+}
+
+/* ---- entry points --------------------------------------------------------------------------- */
+
+/* number of HIP devices visible (0 if none); never fails */
+int rt_device_count(void);
+
+/* Uploads the scene to `device`, builds the triangle BVH.  Caller keeps ownership of all host
+ * arrays (they may be freed after the call returns). */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+
+/* Renders into a HOST buffer of width*height packed 0xFFRRGGBB pixels.  Only pixels whose ray
+ * hit something are written (miss pixels keep the caller's fill, image_buffer.rs:27-37).
+ * Blocks until the buffer is complete.  aux/stats may be NULL; aux pointers are HOST pointers. */
+int rt_render(rt_scene* scene, const rt_params* params, uint32_t* argb, const rt_aux* aux,
+              rt_stats* stats);
+
+/* Same, but `argb_dev` (and aux pointers) are DEVICE pointers on the scene's device and the
+ * launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  stats (if not
+ * NULL) is filled with ray counters only after the caller synchronises AND calls
+ * rt_render_collect_stats. */
+int rt_render_device(rt_scene* scene, const rt_params* params, uint32_t* argb_dev,
+                     const rt_aux* aux_dev, void* hip_stream);
+int rt_render_collect_stats(rt_scene* scene, rt_stats* stats);
+
+void rt_scene_destroy(rt_scene* scene);
+
+/* thread-local message for the last non-RT_OK return on this thread */
+const char* rt_last_error(void);
+
+/* introspection for DESIGN.md / tests: BVH size of a created scene */
+typedef struct rt_bvh_info {
+  uint32_t n_nodes;
+  uint32_t n_leaves;
+  uint32_t max_depth;
+  uint32_t max_leaf_size;
+  uint64_t bytes_nodes;
+  uint64_t bytes_triangles;
+} rt_bvh_info;
+int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

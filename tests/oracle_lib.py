@@ -1,0 +1,69 @@
+"""ctypes access to the CPU oracle (oracle/rt_oracle.c).  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "_build", "librt_oracle.so")
+
+from hslu_i.ba_raytracing.f2501_raytracer_amd import _abi  # noqa: E402
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "rt_oracle.c")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return SO
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    lib = C.CDLL(SO)
+    lib.rt_cpu_render.restype = C.c_int
+    lib.rt_cpu_render.argtypes = [C.POINTER(_abi.rt_scene_desc), C.POINTER(_abi.rt_params), C.c_void_p,
+                                  C.POINTER(_abi.rt_aux), C.POINTER(_abi.rt_stats), C.c_int]
+    fp = C.POINTER(C.c_float)
+    lib.rt_oracle_sphere.restype = C.c_int
+    lib.rt_oracle_sphere.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_uint32, fp, fp, C.c_int, fp]
+    lib.rt_oracle_triangle.restype = C.c_int
+    lib.rt_oracle_triangle.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_uint32, fp, fp, C.c_int, fp]
+    lib.rt_oracle_fresnel.restype = None
+    lib.rt_oracle_fresnel.argtypes = [fp, fp, fp, C.c_float, fp]
+    lib.rt_oracle_atten.restype = C.c_float
+    lib.rt_oracle_atten.argtypes = [C.c_float]
+    lib.rt_oracle_pack.restype = C.c_uint32
+    lib.rt_oracle_pack.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.rt_oracle_refract.restype = None
+    lib.rt_oracle_refract.argtypes = [fp, fp, C.c_float, fp]
+    _lib = lib
+    return lib
+
+
+def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, aa_offsets=None, cloud=None):
+    """Brute-force CPU render of `window` (x0,y0,w,h) of the frame.  Returns (argb, planes, stats)."""
+    lib = load()
+    desc, keep = _abi.make_scene_desc(flat)
+    p, keep2 = _abi.make_params(cfg, aa_offsets=aa_offsets, cloud=cloud, window=window, n_ranks=n_ranks, rank=rank)
+    n = cfg.width * cfg.height
+    argb = np.zeros((n,), np.uint32)
+    planes = {"rgb": np.zeros((n, 3), np.float32), "hit_id": np.full((n,), -2, np.int32), "hit_t": np.zeros((n,), np.float32)}
+    a = _abi.rt_aux()
+    a.rgb, a.hit_id, a.hit_t = planes["rgb"].ctypes.data, planes["hit_id"].ctypes.data, planes["hit_t"].ctypes.data
+    st = _abi.rt_stats()
+    if n_threads is None:
+        n_threads = min(os.cpu_count() or 1, 16)
+    rc = lib.rt_cpu_render(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st), int(n_threads))
+    if rc != 0:
+        raise RuntimeError(f"rt_cpu_render failed: {rc}")
+    return argb, planes, st.as_dict()

@@ -1,0 +1,169 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars: hit ids and pixel indices bit-exact; hit distance bit-exact (same fp32 op sequence, correctly
+rounded div/sqrt on both sides); un-quantised RGB within 1e-4 (BASELINE.json north_star); packed
+pixels may differ by 1 LSB where tanhf/powf differ in the last ulp.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, _abi, scenes
+from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import ImageBuffer, RaytracerRenderer
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+
+
+def window_mask(cfg, win):
+    m = np.zeros((cfg.height, cfg.width), bool)
+    if win is None:
+        m[:] = True
+    else:
+        x0, y0, w, h = win
+        m[y0:y0 + h, x0:x0 + w] = True
+    return m.ravel()
+
+
+def gpu_render(cfg, flat, win=None, traversal=_abi.RT_TRAVERSAL_BVH, n_ranks=1, rank=0):
+    buf = ImageBuffer.new(cfg.width, cfg.height)
+    r = RaytracerRenderer(cfg, device=0, traversal=traversal)
+    planes = r.render(buf, flat, window=win, aux=True, n_ranks=n_ranks, rank=rank)
+    return buf.buffer.copy(), planes, r.last_stats
+
+
+def compare(cfg, flat, win, traversal=_abi.RT_TRAVERSAL_BVH, max_bad_px=0):
+    argb_g, pg, sg = gpu_render(cfg, flat, win, traversal)
+    argb_o, po, so = oracle_lib.render(flat, cfg, window=win)
+    m = window_mask(cfg, win)
+    # pixel indices: exactly the same pixels written, nothing outside the window touched
+    assert np.array_equal(argb_g != 0, argb_o != 0)
+    assert not (argb_g[~m] != 0).any()
+    assert np.array_equal(pg["hit_id"], po["hit_id"]), \
+        f"{(pg['hit_id'] != po['hit_id']).sum()} hit ids differ"
+    hit = m & (po["hit_id"] >= 0)
+    assert np.array_equal(pg["hit_t"][hit].view(np.uint32), po["hit_t"][hit].view(np.uint32)), "hit t not bit-exact"
+    d = np.abs(pg["rgb"] - po["rgb"]).max(axis=1)
+    bad = int((d > RGB_TOL).sum())
+    assert bad <= max_bad_px, f"{bad} pixels exceed {RGB_TOL} (max {d.max():.3e})"
+    # packed pixels: at most 1 LSB per channel
+    for sh in (16, 8, 0):
+        a = ((argb_g >> sh) & 0xFF).astype(np.int32)
+        b = ((argb_o >> sh) & 0xFF).astype(np.int32)
+        assert np.abs(a - b).max() <= 1
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
+        assert sg[k] == so[k], (k, sg[k], so[k])
+    return float(d.max())
+
+
+def test_config1_test_scene_full_frame():
+    """BASELINE config 1 workload on the GPU: test_scene 768x640, no AA / secondary rays."""
+    cfg = RenderConfig.from_features([])
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, None)
+
+
+def test_config2_spheres_only_medium_resolution():
+    """BASELINE config 2: test_scene spheres only, 1140x950, no secondary rays."""
+    cfg = RenderConfig.from_features(["medium_resolution"])
+    flat = scenes.test_scene(cfg).flatten().without_triangles()
+    compare(cfg, flat, None)
+
+
+def test_linear_scan_mode_matches_oracle():
+    cfg = RenderConfig.from_features([])
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (200, 150, 160, 128), traversal=_abi.RT_TRAVERSAL_LINEAR)
+
+
+def test_reflections_refractions_window():
+    cfg = RenderConfig.from_features(["realistic"])
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (280, 160, 192, 160))
+
+
+def test_aa_soft_shadows_window():
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (300, 200, 96, 96))
+
+
+def test_everything_on_window_ragged():
+    """AA + rotation/random table + soft shadows + reflections/refractions; window not aligned to the
+    16x16 workgroup tile and touching the frame corner."""
+    cfg = RenderConfig.from_features(["realistic", "high_quality", "anti_aliasing_randomness",
+                                      "anti_aliasing_rotation_scale"], n_cloud_sets=32, depth_override=4)
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (cfg.width - 37, cfg.height - 29, 37, 29))
+
+
+def test_backface_culling_flag():
+    cfg = RenderConfig.from_features(["backface_culling", "reflections"])
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (250, 200, 128, 96))
+
+
+@pytest.mark.parametrize("model", ["text_lowres"])
+def test_semesterbild_config3_windows(model):
+    """BASELINE config 3 (semesterbild, high_resolution + anti_aliasing + soft_shadows) on windows the
+    brute-force oracle finishes in seconds."""
+    cfg = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.semesterbild(cfg, model).flatten()
+    for win in ((420, 330, 32, 24), (800, 560, 24, 24), (1180, 1010, 32, 16)):
+        compare(cfg, flat, win)
+
+
+def test_semesterbild_realistic_window():
+    cfg = RenderConfig.from_features(["high_resolution", "realistic"], depth_override=8)
+    flat = scenes.semesterbild(cfg, "text_lowres").flatten()
+    compare(cfg, flat, (700, 480, 48, 32))
+
+
+def test_bvh_equals_linear_full_frame_semesterbild():
+    """Size-independent property at full size: the BVH must not change any result of the linear scan."""
+    cfg = RenderConfig.from_features(["high_resolution"])
+    flat = scenes.semesterbild(cfg, "text").flatten()
+    a1, p1, s1 = gpu_render(cfg, flat, None, _abi.RT_TRAVERSAL_BVH)
+    a2, p2, s2 = gpu_render(cfg, flat, (0, 0, cfg.width, 160), _abi.RT_TRAVERSAL_LINEAR)
+    m = window_mask(cfg, (0, 0, cfg.width, 160))
+    assert np.array_equal(p1["hit_id"][m], p2["hit_id"][m])
+    assert np.array_equal(a1[m], a2[m])
+
+
+def test_tile_partition_union_equals_full():
+    """Multi-GPU sharding property: the union of the ranks' tiles is the full frame, tiles disjoint."""
+    cfg = RenderConfig.from_features(["reflections"])
+    flat = scenes.test_scene(cfg).flatten()
+    full, _, sf = gpu_render(cfg, flat)
+    acc = np.zeros_like(full)
+    written = 0
+    for rank in range(3):
+        part, _, sp = gpu_render(cfg, flat, n_ranks=3, rank=rank)
+        assert not ((acc != 0) & (part != 0)).any()
+        acc |= part
+        written += sp["pixels_written"]
+    assert np.array_equal(acc, full)
+    assert written == sf["pixels_written"]
+
+
+def test_empty_scene_and_prefilled_buffer():
+    """Miss pixels are never written (image_buffer.rs:27-37): an empty scene leaves the fill intact."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import Scene
+    cfg = RenderConfig.from_features([])
+    buf = ImageBuffer.new_with_color(cfg.width, cfg.height, 0x12345678)
+    RaytracerRenderer(cfg).render(buf, Scene.new().flatten())
+    assert (buf.buffer == 0x12345678).all()
+
+
+def test_error_paths():
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    d = _abi.rt_scene_desc()
+    assert lib.rt_scene_create(C.byref(d), 0, C.byref(h)) == _abi.RT_ERR_INVALID_ARG  # abi_version 0
+    assert b"abi_version" in lib.rt_last_error()
+    cfg = RenderConfig.from_features([])
+    with pytest.raises(ValueError):
+        RaytracerRenderer(cfg).render(ImageBuffer.new(10, 10), scenes.test_scene(cfg))
