@@ -467,9 +467,7 @@ __device__ __forceinline__ void render_body(const RtDevScene& sc, const RtDevPar
   const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
   bool pix_on = (lx < P.win_w) && (ly < P.win_h);
   if (pix_on && P.n_ranks > 1) {
-    uint32_t tiles_x = (P.width + P.tile_size - 1) / P.tile_size;
-    uint32_t tile = (gy / P.tile_size) * tiles_x + (gx / P.tile_size);
-    pix_on = (rt_tile_perm(tile) % P.n_ranks) == P.rank;
+    pix_on = rt_tile_owner(gx / P.tile_size, gy / P.tile_size, P.n_ranks) == P.rank;
   }
   if (!__ballot(pix_on)) return;  // wave-uniform exit; no block-level barrier is used below
 

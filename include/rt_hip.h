@@ -134,7 +134,7 @@ typedef struct rt_params {
   uint32_t win_x0, win_y0, win_w, win_h;
 
   /* tile ownership for multi-GPU: RENDER_STRIDE x RENDER_STRIDE tiles (renderer/mod.rs:84-90,
-   * image_buffer.rs:48-97); this call renders the tiles t with  perm(t) % n_ranks == rank.
+   * image_buffer.rs:48-97); this call renders the tiles with rt_tile_owner(tx, ty, n_ranks) == rank.
    * n_ranks <= 1 -> all tiles. */
   uint32_t tile_size; /* 0 -> 48 */
   uint32_t n_ranks;
@@ -182,13 +182,24 @@ RT_HOSTDEV static inline uint32_t rt_cloud_hash(uint32_t seed, uint32_t pixel, u
   return h;
 }
 
-/* tile -> owner permutation for multi-GPU interleaving; part of the ABI spec */
-RT_HOSTDEV static inline uint32_t rt_tile_perm(uint32_t tile) {
-  uint32_t h = tile * 0x9E3779B1u;
-  h ^= h >> 15;
-  h *= 0x85EBCA6Bu;
-  h ^= h >> 13;
-  return h;
+/* tile -> owning rank for multi-GPU interleaving; part of the ABI spec.  A lattice interleave
+ * (tx + S*ty) mod n with S the smallest odd number >= 3 coprime to n: neighbouring tiles always
+ * belong to different ranks, so spatial cost hot-spots (glass sphere vs background) spread evenly,
+ * and every rank owns the same number of tiles +-1 per row. */
+RT_HOSTDEV static inline uint32_t rt_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t n_ranks) {
+  if (n_ranks <= 1u) return 0u;
+  uint32_t s = 3u;
+  for (;;) {
+    uint32_t a = s, b = n_ranks;
+    while (b) {
+      uint32_t t = a % b;
+      a = b;
+      b = t;
+    }
+    if (a == 1u) break;
+    s += 2u;
+  }
+  return (tile_x + s * tile_y) % n_ranks;
 }
 
 /* ---- entry points --------------------------------------------------------------------------- */

@@ -585,9 +585,7 @@ typedef struct {
 static int tile_owned(const rt_params* P, uint32_t gx, uint32_t gy) {
   if (P->n_ranks <= 1) return 1;
   uint32_t ts = P->tile_size ? P->tile_size : 48u;
-  uint32_t tiles_x = (P->width + ts - 1) / ts;
-  uint32_t tile = (gy / ts) * tiles_x + (gx / ts);
-  return (rt_tile_perm(tile) % P->n_ranks) == P->rank;
+  return rt_tile_owner(gx / ts, gy / ts, P->n_ranks) == P->rank;
 }
 
 static void* worker(void* arg) {
