@@ -588,6 +588,8 @@ static int tile_owned(const rt_params* P, uint32_t gx, uint32_t gy) {
   return rt_tile_owner(gx / ts, gy / ts, P->n_ranks) == P->rank;
 }
 
+#define RT_CHUNK 8u
+
 static void* worker(void* arg) {
   job_t* j = (job_t*)arg;
   ctx_t c;
@@ -600,11 +602,15 @@ static void* worker(void* arg) {
   c.lpos = (float*)malloc(sizeof(float) * 3 * (nl + 1));
   c.lcol = (float*)malloc(sizeof(float) * 3 * (nl + 1));
   c.lint = (float*)malloc(sizeof(float) * (nl + 1));
+  /* work items: runs of RT_CHUNK pixels in row-major window order (fine-grained so that small
+   * windows still spread over all threads) */
+  const uint32_t total = j->w * j->h;
   for (;;) {
-    uint32_t row = __atomic_fetch_add(j->next_row, 1u, __ATOMIC_RELAXED);
-    if (row >= j->h) break;
-    uint32_t gy = j->y0 + row;
-    for (uint32_t gx = j->x0; gx < j->x0 + j->w; gx++) {
+    uint32_t first = __atomic_fetch_add(j->next_row, RT_CHUNK, __ATOMIC_RELAXED);
+    if (first >= total) break;
+    uint32_t last = first + RT_CHUNK < total ? first + RT_CHUNK : total;
+    for (uint32_t k = first; k < last; k++) {
+      uint32_t gx = j->x0 + k % j->w, gy = j->y0 + k / j->w;
       if (!tile_owned(j->p, gx, gy)) continue;
       render_pixel(&c, gx, gy, j->argb, j->aux, &j->written);
     }
