@@ -52,6 +52,9 @@ class rt_stats(C.Structure):
         ("rays_primary", C.c_uint64), ("rays_reflection", C.c_uint64), ("rays_refraction", C.c_uint64),
         ("rays_shadow", C.c_uint64), ("pixels_written", C.c_uint64),
         ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("wave_ray_passes", C.c_uint64), ("wave_ray_lanes", C.c_uint64),
+        ("wave_nearest_nodes", C.c_uint64), ("wave_nearest_tris", C.c_uint64),
+        ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -1,7 +1,7 @@
 // rt_api.cpp -- the C ABI of include/rt_hip.h over the HIP runtime.
 //
 // rt_scene owns the device copies of the flattened Scene (reference src/scene/scene.rs:24-27), the
-// BVH, and reusable device workspaces (parameter tables, counters, per-thread path stack), so a
+// BVH, and reusable device workspaces (parameter tables, counters, ray queues, accumulator), so a
 // render call performs no allocation when its shape repeats (graph-capture friendly: rt_render_device
 // only enqueues async work on the caller's stream).
 #include <hip/hip_runtime.h>
@@ -70,7 +70,8 @@ struct rt_scene {
   rt_bvh_info info{};
   DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes;
   // per-render workspaces
-  DevBuf aa, cloud, counters, path, fb, aux_rgb, aux_id, aux_t;
+  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t;
+  size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host;
 };
@@ -89,7 +90,7 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
-                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->path, &s->fb, &s->aux_rgb,
+                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -200,7 +201,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     if ((rc = upload(s->lights, l.data(), l.size() * 4)) != RT_OK) return bail(rc);
   }
-  if ((rc = s->counters.ensure(8 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
+  if ((rc = s->counters.ensure(RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
 
   s->dev.spheres = (const float4*)s->spheres.p;
   s->dev.sphere_mat = (const uint32_t*)s->sphere_mat.p;
@@ -306,18 +307,98 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->aux_hit_t = aux_dev->hit_t;
   }
   P->counters = (unsigned long long*)s->counters.p;
-  HIP_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(s->counters.p, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
 
-  const bool secondary = (p->flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
-  uint32_t bx = (P->win_w + RT_BLOCK_W - 1) / RT_BLOCK_W, by = (P->win_h + RT_BLOCK_H - 1) / RT_BLOCK_H;
-  P->path_threads = bx * by * 256u;
-  if (secondary) {
-    uint32_t md = p->max_depth_reflection > p->max_depth_refraction ? p->max_depth_reflection : p->max_depth_refraction;
-    P->path_levels = md + 1;
-    size_t bytes = (size_t)P->path_levels * RT_PATH_FIELDS * 4 * P->path_threads;
-    if ((rc = s->path.ensure(bytes)) != RT_OK) return rc;
-    P->path_stack = (float*)s->path.p;
+  const bool aa_on = P->aa_rays > 0;
+  if (aa_on && P->aa_rays > 256) return fail(RT_ERR_UNSUPPORTED, "aa_rays > 256");
+  return RT_OK;
+}
+
+// ---- frame scheduler -------------------------------------------------------------------------------
+// Without secondary rays a frame is ONE launch of the primary kernel.  With reflections/refractions
+// every child ray becomes an independent work item in HBM ("ray streaming"): the primary kernel and
+// each secondary launch append their children to the next level's queue, and queues are drained
+// deepest level first, so level k+1 never holds more than the children of one chunk of level k
+// (<= 2 * RT_CHUNK = capacity).  Pixel sums use a fixed-point accumulator (order independent,
+// hence bit-reproducible), resolved to packed pixels by a last kernel.
+static const uint32_t RT_CHUNK = 1u << 21;       // rays per secondary launch / per primary batch
+static const uint32_t RT_QUEUE_CAP = 2u * RT_CHUNK;
+
+static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels, hipStream_t stream) {
+  uint32_t n = 0;
+  uint32_t* counts = (uint32_t*)s->qcount.p;
+  HIP_TRY(hipMemcpyAsync(&n, counts + k, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (n == 0) return RT_OK;
+  if (n > RT_QUEUE_CAP) return fail(RT_ERR_HIP, "ray queue %u overflowed (%u rays)", k, n);
+  float4* qbase = (float4*)s->queues.p;
+  const size_t qstride = (size_t)RT_QUEUE_PLANES * RT_QUEUE_CAP;
+  for (uint32_t off = 0; off < n; off += RT_CHUNK) {
+    P.q_in = qbase + (size_t)(k - 1) * qstride;
+    P.q_in_first = off;
+    P.q_in_count = (n - off) < RT_CHUNK ? (n - off) : RT_CHUNK;
+    if (k < levels) {
+      P.q_out = qbase + (size_t)k * qstride;
+      P.q_out_count = counts + k + 1;
+    } else {
+      P.q_out = nullptr;  // rays of the last level have depth 1: no children possible
+      P.q_out_count = nullptr;
+    }
+    hipError_t e = (hipError_t)rt_launch_secondary(s->dev, P, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "secondary launch failed: %s", hipGetErrorString(e));
+    if (k < levels) {
+      int rc = drain_level(s, P, k + 1, levels, stream);
+      if (rc != RT_OK) return rc;
+    }
   }
+  HIP_TRY(hipMemsetAsync(counts + k, 0, 4, stream));
+  return RT_OK;
+}
+
+static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream) {
+  const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
+  const uint32_t total_wgs = rt_primary_total_wgs(P);
+  if (!secondary) {
+    P.acc = nullptr;
+    P.q_out = nullptr;
+    P.batch_first_wg = 0;
+    hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, total_wgs, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return RT_OK;
+  }
+  int rc;
+  const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
+  if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
+  const size_t npix = (size_t)P.width * P.height;
+  if (s->acc_pixels != npix) {
+    if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->acc.p, 0, npix * 4 * sizeof(long long), stream));
+    s->acc_pixels = npix;
+  }
+  const size_t qstride = (size_t)RT_QUEUE_PLANES * RT_QUEUE_CAP;
+  if ((rc = s->queues.ensure((size_t)levels * qstride * sizeof(float4))) != RT_OK) return rc;
+  if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
+  HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));
+  uint32_t* counts = (uint32_t*)s->qcount.p;  // [0] = overflow flag, [k] = rays waiting at level k
+  P.acc = (long long*)s->acc.p;
+  P.q_capacity = RT_QUEUE_CAP;
+  P.q_overflow = counts;
+  const uint32_t batch_wgs = RT_CHUNK / 256u;
+  for (uint32_t w0 = 0; w0 < total_wgs; w0 += batch_wgs) {
+    uint32_t n = (total_wgs - w0) < batch_wgs ? (total_wgs - w0) : batch_wgs;
+    P.batch_first_wg = w0;
+    P.q_out = (float4*)s->queues.p;
+    P.q_out_count = counts + 1;
+    hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, n, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if ((rc = drain_level(s, P, 1, levels, stream)) != RT_OK) return rc;
+  }
+  hipError_t e = (hipError_t)rt_launch_resolve(P, stream);
+  if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+  uint32_t ovf = 0;
+  HIP_TRY(hipMemcpyAsync(&ovf, counts, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (ovf) return fail(RT_ERR_HIP, "%u child rays were dropped (queue overflow)", ovf);
   return RT_OK;
 }
 
@@ -328,21 +409,29 @@ int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const 
   HIP_TRY(hipSetDevice(s->device));
   RtDevParams P;
   if ((rc = prepare(s, p, argb_dev, aux_dev, (hipStream_t)hip_stream, &P)) != RT_OK) return rc;
-  hipError_t e = (hipError_t)rt_launch_render(s->dev, P, hip_stream);
-  if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-  return RT_OK;
+  return render_frame(s, P, (hipStream_t)hip_stream);
 }
 
 int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   if (!s || !st) return fail(RT_ERR_INVALID_ARG, "null argument");
   HIP_TRY(hipSetDevice(s->device));
-  unsigned long long c[8];
-  HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+  unsigned long long all[RT_COUNTER_REPLICAS * 16];
+  HIP_TRY(hipMemcpy(all, s->counters.p, sizeof(all), hipMemcpyDeviceToHost));
+  unsigned long long c[16] = {0};
+  for (unsigned r = 0; r < RT_COUNTER_REPLICAS; r++)
+    for (unsigned i = 0; i < 16; i++) c[i] += all[r * 16 + i];
   st->rays_primary = c[0];
   st->rays_reflection = c[1];
   st->rays_refraction = c[2];
   st->rays_shadow = c[3];
   st->pixels_written = c[4];
+  st->wave_ray_passes = c[5];
+  st->wave_ray_lanes = c[6];
+  st->wave_nearest_nodes = c[7];
+  st->wave_nearest_tris = c[8];
+  st->wave_shadow_nodes = c[9];
+  st->wave_shadow_tris = c[10];
+  st->wave_shadow_passes = c[11];
   return RT_OK;
 }
 
@@ -380,8 +469,7 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
   RtDevParams P;
   if ((rc = prepare(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(e0, nullptr));
-  hipError_t le = (hipError_t)rt_launch_render(s->dev, P, nullptr);
-  if (le != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+  if ((rc = render_frame(s, P, nullptr)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(e1, nullptr));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -79,16 +79,28 @@ struct RtDevParams {
   float* aux_rgb;
   int32_t* aux_hit_id;
   float* aux_hit_t;
-  unsigned long long* counters;  // [5]: primary, reflection, refraction, shadow, pixels written
-  // per-thread path stack (SoA, RT_PATH_FIELDS dwords per level), only when secondary rays are on
-  float* path_stack;
-  uint32_t path_levels;
-  uint32_t path_threads;  // total threads of the launch (stride of the SoA)
+  unsigned long long* counters;  // [RT_COUNTER_REPLICAS][16]: primary, reflection, refraction, shadow, written, wave stats
+  // ---- ray streaming (only when reflections / refractions are enabled) ---------------------------
+  // A queue is 3 float4 planes of q_capacity entries (SoA -> coalesced 16 B/lane accesses):
+  //   plane 0 {o.xyz, n_start}  plane 1 {d.xyz, bits(depth << 2 | kind)}  plane 2 {W.rgb, bits(pixel)}
+  float4* q_out;          // children of this launch are appended here (nullptr: no children wanted)
+  uint32_t* q_out_count;  // device counter of q_out
+  uint32_t* q_overflow;   // device counter of dropped children (must stay 0)
+  uint32_t q_capacity;
+  const float4* q_in;     // secondary kernel: rays [q_in_first, q_in_first + q_in_count)
+  uint32_t q_in_first, q_in_count;
+  long long* acc;         // [W*H][4] fixed-point RGB accumulator + primary-hit flag (nullptr: direct write)
+  uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
 };
 
-#define RT_PATH_FIELDS 12u
 #define RT_BLOCK_W 16u
 #define RT_BLOCK_H 16u
+#define RT_QUEUE_PLANES 3u
+#define RT_COUNTER_REPLICAS 64u
 
-// launches the render kernel on `stream`; returns hipError_t as int
-int rt_launch_render(const RtDevScene& sc, const RtDevParams& p, void* stream);
+// kernel launchers (rt_kernels.hip); return hipError_t as int
+uint32_t rt_primary_pixels_per_wg(const RtDevParams& p);
+uint32_t rt_primary_total_wgs(const RtDevParams& p);
+int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
+int rt_launch_secondary(const RtDevScene& sc, const RtDevParams& p, void* stream);
+int rt_launch_resolve(const RtDevParams& p, void* stream);

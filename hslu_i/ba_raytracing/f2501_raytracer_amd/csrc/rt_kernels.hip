@@ -77,6 +77,22 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) {
 }
 __device__ __forceinline__ bool has_nan(V3 a) { return (a.x != a.x) | (a.y != a.y) | (a.z != a.z); }
 
+// Wave-uniform load: the address is the same in every lane, so read it through the constant address
+// space -> s_load_dwordx4/x8/x16 into SGPRs (scalar cache -> L2) instead of 64 identical vector loads.
+// All scene arrays are read-only for the whole launch, which the scalar cache requires.
+template <class T>
+__device__ __forceinline__ T uload(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records only");
+  typedef const uint32_t __attribute__((address_space(4))) * CP;
+  CP q = (CP)(uintptr_t)p;
+  uint32_t w[sizeof(T) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = q[i];
+  T v;
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
+
 struct Mat {
   V3 color;
   float metallic, shininess, ior, opacity, boost;
@@ -87,6 +103,22 @@ __device__ __forceinline__ Mat load_mat(const RtDevScene& sc, uint32_t idx) {
   const float4 a = sc.materials[3 * idx + 0];
   const float4 b = sc.materials[3 * idx + 1];
   const float4 c = sc.materials[3 * idx + 2];
+  Mat m;
+  m.color = mk(a.x, a.y, a.z);
+  m.metallic = a.w;
+  m.shininess = b.x;
+  m.ior = b.y;
+  m.opacity = b.z;
+  m.boost = b.w;
+  m.transmissive = (c.x != 0.0f) && !(fabsf(m.opacity - 0.0f) <= RT_EPS);
+  return m;
+}
+
+// same, material index wave-uniform
+__device__ __forceinline__ Mat load_mat_u(const RtDevScene& sc, uint32_t idx) {
+  const float4 a = uload(&sc.materials[3 * idx + 0]);
+  const float4 b = uload(&sc.materials[3 * idx + 1]);
+  const float4 c = uload(&sc.materials[3 * idx + 2]);
   Mat m;
   m.color = mk(a.x, a.y, a.z);
   m.metallic = a.w;
@@ -221,6 +253,8 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
 
 struct WaveCtx {
   uint32_t* stack;  // this wavefront's traversal stack in LDS
+  // wave-level work counters (uniform)
+  unsigned long long n_nodes, n_tris, s_nodes, s_tris, s_passes;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -233,13 +267,13 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   best.t = INFINITY;
   best.id = -1;
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
-    float4 s = sc.spheres[i];
+    float4 s = uload(&sc.spheres[i]);
     float t;
     bool h = alive && sphere_hit(s, o, d, t);
     if (CULL && h) {  // sphere.rs:137-151
       V3 p = fma_s(d, t, o);
       V3 n = normalize(p - mk(s.x, s.y, s.z));
-      Mat m = load_mat(sc, sc.sphere_mat[i]);
+      Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
       h = (dot(d, n) < 0.75f) || m.transmissive;
     }
     if (h && t <= best.t) {
@@ -251,20 +285,20 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   const int tri_base = (int)sc.n_spheres;
 
   auto test_tri = [&](uint32_t slot, bool lane_on) {
-    float4 q0 = sc.tri_isect[3 * slot + 0];
-    float4 q1 = sc.tri_isect[3 * slot + 1];
-    float4 q2 = sc.tri_isect[3 * slot + 2];
+    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
+    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
+    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
     float t;
     bool h = lane_on && tri_hit(q0, q1, q2, o, d, t);
     if (CULL) {  // triangle.rs:154-168
       if (__ballot(h)) {
-        float4 sh = sc.tri_shade[slot];
-        Mat m = load_mat(sc, __float_as_uint(sh.w));
+        float4 sh = uload(&sc.tri_shade[slot]);
+        Mat m = load_mat_u(sc, __float_as_uint(sh.w));
         h = h && ((dot(d, mk(sh.x, sh.y, sh.z)) < 0.75f) || m.transmissive);
       }
     }
     if (__ballot(h)) {
-      int id = tri_base + (int)sc.tri_id[slot];
+      int id = tri_base + (int)uload(&sc.tri_id[slot]);
       if (h && (t < best.t || (t == best.t && id > best.id))) {
         best.t = t;
         best.id = id;
@@ -281,7 +315,8 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   uint32_t sp = 0;
   uint32_t node = 0;
   for (;;) {
-    const RtNode nd = sc.nodes[node];
+    const RtNode nd = uload(&sc.nodes[node]);
+    W.n_nodes++;
     float tn0, tn1;
     bool h0 = alive && box_hit(nd.lo0, nd.hi0, o, inv, best.t, tn0);
     bool h1 = alive && box_hit(nd.lo1, nd.hi1, o, inv, best.t, tn1);
@@ -290,6 +325,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
     bool in0 = false, in1 = false;  // internal children to descend into
     if (b0) {
       if (nd.n0) {
+        W.n_tris += nd.n0;
         for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
       } else {
         in0 = true;
@@ -297,6 +333,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
     }
     if (b1) {
       if (nd.n1) {
+        W.n_tris += nd.n1;
         for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
       } else {
         in1 = true;
@@ -340,7 +377,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   S.filter = mk(1.0f, 1.0f, 1.0f);
   V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
-    float4 s = sc.spheres[i];
+    float4 s = uload(&sc.spheres[i]);
     float t;
     bool h = alive && !S.occluded && sphere_hit(s, o, d, t);
     h = h && (t <= tmax);
@@ -348,7 +385,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (h) {
         V3 p = fma_s(d, t, o);
         V3 n = normalize(p - mk(s.x, s.y, s.z));
-        Mat m = load_mat(sc, sc.sphere_mat[i]);
+        Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
         bool vis = true;
         if (CULL) vis = (dot(d, n) < 0.75f) || m.transmissive;
         if (vis) shadow_accumulate(S, m, n, d);
@@ -358,15 +395,15 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   if (sc.n_triangles == 0) return S;
 
   auto test_tri = [&](uint32_t slot, bool lane_on) {
-    float4 q0 = sc.tri_isect[3 * slot + 0];
-    float4 q1 = sc.tri_isect[3 * slot + 1];
-    float4 q2 = sc.tri_isect[3 * slot + 2];
+    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
+    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
+    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
     float t;
     bool h = lane_on && !S.occluded && tri_hit(q0, q1, q2, o, d, t);
     h = h && (t <= tmax);
     if (__ballot(h)) {
-      float4 sh = sc.tri_shade[slot];
-      Mat m = load_mat(sc, __float_as_uint(sh.w));
+      float4 sh = uload(&sc.tri_shade[slot]);
+      Mat m = load_mat_u(sc, __float_as_uint(sh.w));
       V3 n = mk(sh.x, sh.y, sh.z);
       if (CULL) h = h && ((dot(d, n) < 0.75f) || m.transmissive);
       if (h) shadow_accumulate(S, m, n, d);
@@ -381,11 +418,13 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   V3 inv = mk(__frcp_rn(d.x), __frcp_rn(d.y), __frcp_rn(d.z));
   uint32_t sp = 0;
   uint32_t node = 0;
+  W.s_passes++;
   for (;;) {
-    const RtNode nd = sc.nodes[node];
+    const RtNode nd = uload(&sc.nodes[node]);
     float tn0, tn1;
     bool live = alive && !S.occluded;
     if (!__ballot(live)) break;
+    W.s_nodes++;
     bool h0 = live && box_hit(nd.lo0, nd.hi0, o, inv, tmax, tn0);
     bool h1 = live && box_hit(nd.lo1, nd.hi1, o, inv, tmax, tn1);
     unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
@@ -393,6 +432,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     bool in0 = false, in1 = false;
     if (b0) {
       if (nd.n0) {
+        W.s_tris += nd.n0;
         for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
       } else {
         in0 = true;
@@ -400,6 +440,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     }
     if (b1) {
       if (nd.n1) {
+        W.s_tris += nd.n1;
         for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
       } else {
         in1 = true;
@@ -452,299 +493,487 @@ __device__ __forceinline__ uint32_t to_u8(float x) {
 
 enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
 
-template <bool CULL>
-__device__ __forceinline__ void render_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  WaveCtx W;
-  W.stack = lds_stack + wave * RT_STACK_DEPTH;
+// fixed-point pixel accumulator used when secondary rays are streamed: integer adds are
+// associative, so the per-pixel sum does not depend on the order in which rays retire
+#define RT_ACC_SCALE 68719476736.0f /* 2^36 */
+#define RT_ACC_INV_SCALE (1.0f / 68719476736.0f)
 
-  // 16x16 pixel block, each wave an 8x8 tile
-  const uint32_t blocks_x = (P.win_w + RT_BLOCK_W - 1) / RT_BLOCK_W;
-  const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
-  const uint32_t lx = bx * RT_BLOCK_W + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t ly = by * RT_BLOCK_H + (wave >> 1) * 8u + (lane >> 3);
-  const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
-  bool pix_on = (lx < P.win_w) && (ly < P.win_h);
-  if (pix_on && P.n_ranks > 1) {
-    pix_on = rt_tile_owner(gx / P.tile_size, gy / P.tile_size, P.n_ranks) == P.rank;
-  }
-  if (!__ballot(pix_on)) return;  // wave-uniform exit; no block-level barrier is used below
+struct Wave {
+  WaveCtx ctx;
+  unsigned long long cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes;
+};
 
-  const uint32_t pix = gy * P.width + gx;
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const float x = (float)gx * P.fw;  // renderer/mod.rs:176-180
-  const float y = (float)gy * P.fh;
-  const V3 coords = mk(x, y, 0.0f);
-  const V3 D = coords - mk(P.focus[0], P.focus[1], P.focus[2]);
-  const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
-  const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
-  const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
-  const uint32_t n_samples = aa ? P.aa_rays : 1u;
-  const float scale = aa ? 1.0f / (float)(((n_samples + 7u) / 8u) * 8u) : 1.0f;
-  const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0 && P.path_levels > 0;
+__device__ __forceinline__ void wave_init(Wave& w, uint32_t* lds_stack) {
+  w.ctx.stack = lds_stack + (threadIdx.x >> 6) * RT_STACK_DEPTH;
+  w.ctx.n_nodes = w.ctx.n_tris = w.ctx.s_nodes = w.ctx.s_tris = w.ctx.s_passes = 0;
+  w.cnt_kind[0] = w.cnt_kind[1] = w.cnt_kind[2] = 0;
+  w.cnt_shadow = w.cnt_pass = w.cnt_lanes = 0;
+}
 
-  unsigned long long cnt_primary = 0, cnt_refl = 0, cnt_refr = 0, cnt_shadow = 0;
-  V3 pixel = mk(0.0f, 0.0f, 0.0f);
-  bool any_hit = false;
-  int id0 = -1;
-  float t0 = 0.0f;
-
-  for (uint32_t k = 0; k < n_samples; k++) {
-    // current ray of this lane
-    V3 o = coords, d_raw = D;
-    if (aa) {
-      o.x = coords.x + P.aa_offsets[2 * k];
-      o.y = coords.y + P.aa_offsets[2 * k + 1];
-    }
-    float n_start = P.air_ior;
-    int depth = -1;  // Option<usize>::None
-    int kind = KIND_PRIMARY;
-    V3 Wt = mk(scale, scale, scale);  // path weight
-    bool have = pix_on;
-    uint32_t level = 0;  // entries on this lane's path stack
-
-    // iterate the Whitted tree: wave loops while any lane still has a ray
-    while (__ballot(have)) {
-      V3 d = normalize(d_raw);  // Ray::new_with_mask, ray.rs:52-57
-      bool alive = have && !has_nan(d);
-      // ray accounting: lanes entering cast_ray, by kind (kinds differ per lane once trees diverge)
-      cnt_primary += (unsigned long long)__popcll(__ballot(alive && kind == KIND_PRIMARY));
-      cnt_refl += (unsigned long long)__popcll(__ballot(alive && kind == KIND_REFL));
-      cnt_refr += (unsigned long long)__popcll(__ballot(alive && kind == KIND_REFR));
-
-      Hit h = nearest_hit<CULL>(sc, P, W, alive, o, d);
-      bool hit = alive && h.id >= 0;
-      if (kind == KIND_PRIMARY && have) {
-        if (hit) any_hit = true;
-        if (k == 0) {
-          id0 = hit ? h.id : -1;
-          t0 = h.t;
-        }
-      }
-
-      bool spawn_refl = false, spawn_refr = false;
-      V3 refl_o, refl_d, refl_W, refr_o, refr_d, refr_W;
-      float refr_ior = 0.0f;
-      int refl_depth = 0, refr_depth = 0;
-
-      if (__ballot(hit)) {
-        Surf sf;
-        Mat m;
-        sf.p = mk(0, 0, 0);
-        sf.n = mk(0, 0, 1);
-        sf.mat = 0;
-        if (hit) sf = surface_of(sc, h, o, d);
-        m = load_mat(sc, sf.mat);
-        // a reflection child's weight carries atten(child.t), known only now (:722-726)
-        float a = atten(h.t);
-        if (kind == KIND_REFL) Wt = Wt * a;
-
-        // ---- calculate_lighting, raytracer_renderer.rs:731-874 ------------------------------
-        V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
-        const bool has_spec = m.shininess > 0.0f;
-        for (uint32_t l = 0; l < sc.n_lights; l++) {
-          const float4 L0 = sc.lights[2 * l + 0];
-          const float4 L1 = sc.lights[2 * l + 1];
-          const V3 lc = mk(L1.x, L1.y, L1.z);
-          const float* cs = nullptr;
-          float lI = L0.w;
-          if (N > 1) {
-            uint32_t set = rt_cloud_hash(P.cloud_seed, pix, l) % P.n_cloud_sets;
-            cs = P.cloud_sets + (size_t)set * N * 3u;
-            lI = (1.0f / (float)N) * L0.w;
-          }
-          for (uint32_t j = 0; j < N; j++) {
-            V3 lp = mk(L0.x, L0.y, L0.z);
-            if (N > 1 && hit) {
-              lp.x = L0.x + cs[3 * j + 0] * P.fw;  // light.rs:218
-              lp.y = L0.y + cs[3 * j + 1] * P.fh;
-              lp.z = L0.z + cs[3 * j + 2] * P.fd;
-            }
-            V3 ltp = lp - sf.p;
-            V3 ld = normalize(ltp);
-            V3 so = sf.p + ld * epsv;
-            float tmax = mag(lp - so);
-            cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
-            Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax);
-            bool reach = hit && !S.occluded;
-            if (!__ballot(reach)) continue;
-            // PointLight::calculate_contribution_at, light.rs:261-299
-            float dist = mag(ltp) + RT_EPS;
-            float cosi = dot(ltp, sf.n) / dist;
-            bool pos = cosi > 0.0f;
-            float att = 0.95f * (RT_EPS + dist + dist * dist);
-            float sig = (tanhf(att) + 1.0f) / 2.0f;
-            float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
-            V3 ccol = pos ? (m.color * lc) : mk(0, 0, 0);
-            float cint = pos ? lf : 0.0f;
-            V3 Lc = ccol / S.filter;
-            float diff = fmaxf(dot(sf.n, ld), 0.0f);
-            float specf = 0.0f;
-            if (has_spec) {
-              V3 rr = normalize(reflected(ld, sf.n));
-              float base = fmaxf(dot(rr, d), 0.0f);
-              specf = powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
-            }
-            float light_factor = diff * cint * S.opacity;
-            float spec_factor = cint * S.opacity * specf;
-            if (reach && diff > 0.0f) {
-              light_color = light_color + (m.color * Lc) * light_factor;
-              if (has_spec) spec_color = spec_color + lc * spec_factor;
-            }
-          }
-        }
-        V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
-        V3 direct = (ambient + light_color) * a;  // :206-209
-        V3 spec = spec_color * a;
-
-        if (hit) {
-          // own terms of this node (:251-257): transmissive ? spec : direct + spec
-          V3 own = m.transmissive ? spec : (direct + spec);
-          pixel = pixel + Wt * own;
-
-          const bool T = m.transmissive;
-          const bool R = (m.metallic > 0.0f) || T;
-          // ---- calculate_reflection, :526-729 ------------------------------------------------
-          if ((P.flags & RT_FLAG_REFLECTIONS) && R && secondary) {
-            float cos_theta = dot(d, sf.n);
-            bool inside = cos_theta < 0.0f;
-            V3 inormal = inside ? -sf.n : sf.n;
-            float n2 = inside ? m.ior : P.air_ior;
-            float eta = inside ? (n2 / n_start) : (n_start / n2);
-            float cos_i = fabsf(cos_theta);
-            float sin2 = eta * eta * (1.0f - cos_i * cos_i);
-            bool tir = sin2 >= 1.0f;
-            bool reflective = (m.metallic > 0.0f) || (T && tir);
-            int cd = depth < 0 ? (int)P.max_depth_reflection : (depth > 0 ? depth - 1 : 0);
-            if (reflective && cd > 0) {
-              V3 r = normalize(reflected(d, sf.n));
-              V3 Rf = fresnel_reflectance(m, inormal, -d, n_start);
-              spawn_refl = true;
-              refl_o = sf.p + r * epsv;
-              refl_d = r;
-              refl_W = Wt * Rf;
-              refl_depth = cd;
-            }
-          }
-          // ---- calculate_refractions, :279-524 -----------------------------------------------
-          if ((P.flags & RT_FLAG_REFRACTIONS) && T && secondary) {
-            float cos_theta = dot(d, sf.n);
-            bool inside = cos_theta <= 0.0f;
-            V3 inormal = inside ? -sf.n : sf.n;
-            float n2 = inside ? m.ior : P.air_ior;
-            float eta = inside ? (n2 / n_start) : (n_start / n2);
-            float inv_eta = 1.0f / eta;
-            V3 Rf = fresnel_reflectance(m, inormal, d, inv_eta);
-            V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
-            // ultraviolet refracted(n = -inormal, eta = 1/eta)
-            V3 nn = -inormal;
-            float ndi = dot(nn, d);
-            float kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
-            float op = m.opacity;
-            int step = (op < 0.5f) ? 2 : 1;
-            int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
-            int cd = depth < 0 ? (int)P.max_depth_refraction / fac : (depth > step ? depth - step : 0);
-            if (!(kk < 0.0f) && cd > 0) {  // kk < 0: zero vector -> NaN direction -> miss (D2)
-              float s = inv_eta * ndi + __builtin_sqrtf(kk);
-              V3 q = normalize(d * inv_eta - nn * s);
-              spawn_refr = true;
-              refr_o = sf.p + q * epsv;
-              refr_d = q;
-              refr_W = (Wt * (m.boost + 1.0f)) * Tr;
-              refr_ior = n2;
-              refr_depth = cd;
-            }
-          }
-        }
-      }
-
-      // ---- next ray of this lane: child, or pop, or done --------------------------------------
-      if (have) {
-        if (spawn_refl && spawn_refr) {
-          // push the refraction child, continue with the reflection child
-          float* ps = P.path_stack + (size_t)level * RT_PATH_FIELDS * P.path_threads + tid;
-          const size_t st = P.path_threads;
-          ps[0 * st] = refr_o.x;
-          ps[1 * st] = refr_o.y;
-          ps[2 * st] = refr_o.z;
-          ps[3 * st] = refr_d.x;
-          ps[4 * st] = refr_d.y;
-          ps[5 * st] = refr_d.z;
-          ps[6 * st] = refr_ior;
-          ps[7 * st] = refr_W.x;
-          ps[8 * st] = refr_W.y;
-          ps[9 * st] = refr_W.z;
-          ps[10 * st] = __int_as_float(refr_depth);
-          ps[11 * st] = __int_as_float(KIND_REFR);
-          level++;
-        }
-        if (spawn_refl) {
-          o = refl_o;
-          d_raw = refl_d;
-          Wt = refl_W;
-          depth = refl_depth;
-          kind = KIND_REFL;
-        } else if (spawn_refr) {
-          o = refr_o;
-          d_raw = refr_d;
-          Wt = refr_W;
-          n_start = refr_ior;
-          depth = refr_depth;
-          kind = KIND_REFR;
-        } else if (level > 0) {
-          level--;
-          const float* ps = P.path_stack + (size_t)level * RT_PATH_FIELDS * P.path_threads + tid;
-          const size_t st = P.path_threads;
-          o = mk(ps[0 * st], ps[1 * st], ps[2 * st]);
-          d_raw = mk(ps[3 * st], ps[4 * st], ps[5 * st]);
-          n_start = ps[6 * st];
-          Wt = mk(ps[7 * st], ps[8 * st], ps[9 * st]);
-          depth = __float_as_int(ps[10 * st]);
-          kind = __float_as_int(ps[11 * st]);
-        } else {
-          have = false;
-        }
-      }
-    }
-  }
-
-  if (pix_on) {
-    if (P.aux_hit_id) P.aux_hit_id[pix] = id0;
-    if (P.aux_hit_t && id0 >= 0) P.aux_hit_t[pix] = t0;
-    if (any_hit) {
-      P.argb[pix] = 0xFF000000u | (to_u8(pixel.x) << 16) | (to_u8(pixel.y) << 8) | to_u8(pixel.z);
-      if (P.aux_rgb) {
-        P.aux_rgb[3 * (size_t)pix + 0] = pixel.x;
-        P.aux_rgb[3 * (size_t)pix + 1] = pixel.y;
-        P.aux_rgb[3 * (size_t)pix + 2] = pixel.z;
-      }
-    }
-  }
-  unsigned long long written = (unsigned long long)__popcll(__ballot(pix_on && any_hit));
-  if (lane == 0 && P.counters) {
-    atomicAdd(&P.counters[0], cnt_primary);
-    atomicAdd(&P.counters[1], cnt_refl);
-    atomicAdd(&P.counters[2], cnt_refr);
-    atomicAdd(&P.counters[3], cnt_shadow);
-    atomicAdd(&P.counters[4], written);
+__device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, unsigned long long written) {
+  if ((threadIdx.x & 63u) == 0 && P.counters) {
+    // RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
+    // critical path (hundreds of thousands of wavefronts retire per frame); the host sums them
+    unsigned long long* c = P.counters + (size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u;
+    atomicAdd(&c[0], w.cnt_kind[0]);
+    atomicAdd(&c[1], w.cnt_kind[1]);
+    atomicAdd(&c[2], w.cnt_kind[2]);
+    atomicAdd(&c[3], w.cnt_shadow);
+    if (written) atomicAdd(&c[4], written);
+    atomicAdd(&c[5], w.cnt_pass);
+    atomicAdd(&c[6], w.cnt_lanes);
+    atomicAdd(&c[7], w.ctx.n_nodes);
+    atomicAdd(&c[8], w.ctx.n_tris);
+    atomicAdd(&c[9], w.ctx.s_nodes);
+    atomicAdd(&c[10], w.ctx.s_tris);
+    atomicAdd(&c[11], w.ctx.s_passes);
   }
 }
 
-__global__ __launch_bounds__(256) void rt_render_kernel(RtDevScene sc, RtDevParams P) {
+// One ray in flight: a node of the Whitted tree (single_raytrace, raytracer_renderer.rs:147-264)
+struct RayIn {
+  V3 o, d_raw;    // origin, un-normalised direction (Ray::new_with_mask normalises)
+  float n_start;  // refraction index of the medium the ray travels in
+  V3 Wt;          // RGB weight of this node's colour in the pixel sum
+  int depth;      // Option<usize>: -1 = None
+  int kind;
+  uint32_t pix;
+};
+
+struct RayOut {
+  bool hit;
+  float t;
+  int id;
+  V3 contrib;  // Wt * own terms of this node (zero on miss)
+};
+
+// appends the lanes with `on` to the ray queue (wave-level compaction: one atomic per wavefront)
+__device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, V3 d, float n_start, V3 Wt,
+                                           int depth, int kind, uint32_t pix) {
+  unsigned long long m = __ballot(on);
+  if (!m) return;
+  uint32_t n = (uint32_t)__popcll(m);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63u) == 0) base = atomicAdd(P.q_out_count, n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  uint32_t rankl = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  if (on) {
+    uint32_t i = base + rankl;
+    if (i < P.q_capacity) {
+      P.q_out[0 * (size_t)P.q_capacity + i] = make_float4(o.x, o.y, o.z, n_start);
+      P.q_out[1 * (size_t)P.q_capacity + i] = make_float4(d.x, d.y, d.z, __int_as_float((depth << 2) | kind));
+      P.q_out[2 * (size_t)P.q_capacity + i] = make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix));
+    } else {
+      atomicAdd(P.q_overflow, 1u);  // host sizes batches so this cannot happen; reported as an error
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
+                                              const RayIn& r) {
+  RayOut out;
+  out.hit = false;
+  out.t = 0.0f;
+  out.id = -1;
+  out.contrib = mk(0.0f, 0.0f, 0.0f);
+  WaveCtx& W = wv.ctx;
+  const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
+  const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
+  const bool stream = P.q_out != nullptr;
+
+  V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
+  bool alive = have && !has_nan(d);
+  unsigned long long bal = __ballot(alive);
+  if (!bal) return out;
+  // ray accounting: lanes entering cast_ray, by kind
+  wv.cnt_kind[0] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
+  wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
+  wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
+  wv.cnt_pass += 1;
+  wv.cnt_lanes += (unsigned long long)__popcll(bal);
+
+  Hit h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
+  bool hit = alive && h.id >= 0;
+  out.hit = hit;
+  out.t = h.t;
+  out.id = hit ? h.id : -1;
+  if (!__ballot(hit)) return out;
+
+  Surf sf;
+  sf.p = mk(0, 0, 0);
+  sf.n = mk(0, 0, 1);
+  sf.mat = 0;
+  if (hit) sf = surface_of(sc, h, r.o, d);
+  Mat m = load_mat(sc, sf.mat);
+  // a reflection child's weight carries atten(child.t), known only now (:722-726)
+  float a = atten(h.t);
+  V3 Wt = r.Wt;
+  if (r.kind == KIND_REFL) Wt = Wt * a;
+
+  // ---- calculate_lighting, raytracer_renderer.rs:731-874 ----------------------------------------
+  V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
+  const bool has_spec = m.shininess > 0.0f;
+  for (uint32_t l = 0; l < sc.n_lights; l++) {
+    const float4 L0 = uload(&sc.lights[2 * l + 0]);
+    const float4 L1 = uload(&sc.lights[2 * l + 1]);
+    const V3 lc = mk(L1.x, L1.y, L1.z);
+    const float* cs = nullptr;
+    float lI = L0.w;
+    if (N > 1) {
+      uint32_t set = rt_cloud_hash(P.cloud_seed, r.pix, l) % P.n_cloud_sets;
+      cs = P.cloud_sets + (size_t)set * N * 3u;
+      lI = (1.0f / (float)N) * L0.w;
+    }
+    for (uint32_t j = 0; j < N; j++) {
+      V3 lp = mk(L0.x, L0.y, L0.z);
+      if (N > 1 && hit) {
+        lp.x = L0.x + cs[3 * j + 0] * P.fw;  // light.rs:218
+        lp.y = L0.y + cs[3 * j + 1] * P.fh;
+        lp.z = L0.z + cs[3 * j + 2] * P.fd;
+      }
+      V3 ltp = lp - sf.p;
+      V3 ld = normalize(ltp);
+      V3 so = sf.p + ld * epsv;
+      float tmax = mag(lp - so);
+      wv.cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
+      Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax);
+      bool reach = hit && !S.occluded;
+      if (!__ballot(reach)) continue;
+      // PointLight::calculate_contribution_at, light.rs:261-299
+      float dist = mag(ltp) + RT_EPS;
+      float cosi = dot(ltp, sf.n) / dist;
+      bool pos = cosi > 0.0f;
+      float att = 0.95f * (RT_EPS + dist + dist * dist);
+      float sig = (tanhf(att) + 1.0f) / 2.0f;
+      float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
+      V3 ccol = pos ? (m.color * lc) : mk(0, 0, 0);
+      float cint = pos ? lf : 0.0f;
+      V3 Lc = ccol / S.filter;
+      float diff = fmaxf(dot(sf.n, ld), 0.0f);
+      float specf = 0.0f;
+      if (has_spec) {
+        V3 rr = normalize(reflected(ld, sf.n));
+        float base = fmaxf(dot(rr, d), 0.0f);
+        specf = powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
+      }
+      float light_factor = diff * cint * S.opacity;
+      float spec_factor = cint * S.opacity * specf;
+      if (reach && diff > 0.0f) {
+        light_color = light_color + (m.color * Lc) * light_factor;
+        if (has_spec) spec_color = spec_color + lc * spec_factor;
+      }
+    }
+  }
+  V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
+  V3 direct = (ambient + light_color) * a;  // :206-209
+  V3 spec = spec_color * a;
+
+  // own terms of this node (:251-257): transmissive ? spec : direct + spec
+  const bool T = m.transmissive;
+  if (hit) {
+    V3 own = T ? spec : (direct + spec);
+    out.contrib = Wt * own;
+  }
+  if (!stream) return out;
+
+  // ---- calculate_reflection, :526-729 -------------------------------------------------------------
+  {
+    bool spawn = false;
+    V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
+    int cdepth = 0;
+    const bool R = (m.metallic > 0.0f) || T;
+    if (hit && (P.flags & RT_FLAG_REFLECTIONS) && R) {
+      float cos_theta = dot(d, sf.n);
+      bool inside = cos_theta < 0.0f;
+      V3 inormal = inside ? -sf.n : sf.n;
+      float n2 = inside ? m.ior : P.air_ior;
+      float eta = inside ? (n2 / r.n_start) : (r.n_start / n2);
+      float cos_i = fabsf(cos_theta);
+      float sin2 = eta * eta * (1.0f - cos_i * cos_i);
+      bool tir = sin2 >= 1.0f;
+      bool reflective = (m.metallic > 0.0f) || (T && tir);
+      cdepth = r.depth < 0 ? (int)P.max_depth_reflection : (r.depth > 0 ? r.depth - 1 : 0);
+      if (reflective && cdepth > 0) {
+        V3 rr = normalize(reflected(d, sf.n));
+        V3 Rf = fresnel_reflectance(m, inormal, -d, r.n_start);
+        spawn = true;
+        co = sf.p + rr * epsv;
+        cd = rr;
+        cW = Wt * Rf;
+      }
+    }
+    queue_push(P, spawn, co, cd, r.n_start, cW, cdepth, KIND_REFL, r.pix);
+  }
+  // ---- calculate_refractions, :279-524 --------------------------------------------------------------
+  {
+    bool spawn = false;
+    V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
+    int cdepth = 0;
+    float cior = 0.0f;
+    if (hit && (P.flags & RT_FLAG_REFRACTIONS) && T) {
+      float cos_theta = dot(d, sf.n);
+      bool inside = cos_theta <= 0.0f;
+      V3 inormal = inside ? -sf.n : sf.n;
+      float n2 = inside ? m.ior : P.air_ior;
+      float eta = inside ? (n2 / r.n_start) : (r.n_start / n2);
+      float inv_eta = 1.0f / eta;
+      V3 Rf = fresnel_reflectance(m, inormal, d, inv_eta);
+      V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
+      // ultraviolet refracted(n = -inormal, eta = 1/eta)
+      V3 nn = -inormal;
+      float ndi = dot(nn, d);
+      float kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
+      float op = m.opacity;
+      int step = (op < 0.5f) ? 2 : 1;
+      int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
+      cdepth = r.depth < 0 ? (int)P.max_depth_refraction / fac : (r.depth > step ? r.depth - step : 0);
+      if (!(kk < 0.0f) && cdepth > 0) {  // kk < 0: zero vector -> NaN direction -> miss (deviation D2)
+        float s = inv_eta * ndi + __builtin_sqrtf(kk);
+        V3 q = normalize(d * inv_eta - nn * s);
+        spawn = true;
+        co = sf.p + q * epsv;
+        cd = q;
+        cW = (Wt * (m.boost + 1.0f)) * Tr;
+        cior = n2;
+      }
+    }
+    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, r.pix);
+  }
+  return out;
+}
+
+__device__ __forceinline__ uint32_t pack_argb(V3 c) {
+  return 0xFF000000u | (to_u8(c.x) << 16) | (to_u8(c.y) << 8) | to_u8(c.z);
+}
+
+__device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c) {
+  long long* a = P.acc + 4 * (size_t)pix;
+  atomicAdd((unsigned long long*)&a[0], (unsigned long long)__float2ll_rn(c.x * RT_ACC_SCALE));
+  atomicAdd((unsigned long long*)&a[1], (unsigned long long)__float2ll_rn(c.y * RT_ACC_SCALE));
+  atomicAdd((unsigned long long*)&a[2], (unsigned long long)__float2ll_rn(c.z * RT_ACC_SCALE));
+}
+
+// ------------------------------------------------------------------------------------------------
+// primary kernel: one thread per (pixel, AA sample).  A 256-thread workgroup owns
+// ppw = 256 / n_samples consecutive pixels in "tile order" (16x16 super-tiles of 4x4 tiles), so a
+// wavefront's 64 camera rays are the samples of a few adjacent pixels -- maximally coherent for the
+// wave-cooperative traversal.  Sample colours meet in LDS and are summed per pixel in the
+// reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack,
+                                             float4* lds_rgbh) {
+  Wave wv;
+  wave_init(wv, lds_stack);
+  const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
+  const uint32_t n_samples = aa ? P.aa_rays : 1u;
+  const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
+  const uint32_t slot = threadIdx.x / n_samples;
+  const uint32_t k = threadIdx.x - slot * n_samples;
+  const bool lane_used = slot < ppw;
+  // pixel index in tile order -> window coordinates
+  const uint32_t st_x = (P.win_w + 15u) / 16u;
+  const uint32_t lin = (P.batch_first_wg + blockIdx.x) * ppw + slot;
+  const uint32_t sup = lin >> 8, in_sup = lin & 255u;
+  const uint32_t t4 = in_sup >> 4, p4 = in_sup & 15u;
+  const uint32_t lx = (sup % st_x) * 16u + (t4 & 3u) * 4u + (p4 & 3u);
+  const uint32_t ly = (sup / st_x) * 16u + (t4 >> 2) * 4u + (p4 >> 2);
+  const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
+  bool pix_on = lane_used && (lx < P.win_w) && (ly < P.win_h);
+  if (pix_on && P.n_ranks > 1) pix_on = rt_tile_owner(gx / P.tile_size, gy / P.tile_size, P.n_ranks) == P.rank;
+
+  const uint32_t pix = gy * P.width + gx;
+  const float x = (float)gx * P.fw;  // renderer/mod.rs:176-180
+  const float y = (float)gy * P.fh;
+  const V3 coords = mk(x, y, 0.0f);
+  RayIn r;
+  r.o = coords;
+  if (aa && pix_on) {
+    r.o.x = coords.x + P.aa_offsets[2 * k];
+    r.o.y = coords.y + P.aa_offsets[2 * k + 1];
+  }
+  r.d_raw = coords - mk(P.focus[0], P.focus[1], P.focus[2]);  // un-jittered for every sample (:1204)
+  r.n_start = P.air_ior;
+  const float scale = aa ? 1.0f / (float)(((n_samples + 7u) / 8u) * 8u) : 1.0f;  // :936-937
+  r.Wt = mk(scale, scale, scale);  // the sample's 1/total_rays weight rides along the whole tree
+  r.depth = -1;
+  r.kind = KIND_PRIMARY;
+  r.pix = pix;
+
+  RayOut out = process_ray<CULL>(sc, P, wv, pix_on, r);
+
+  // ---- per-pixel accumulation of the samples ----------------------------------------------------------
+  V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
+  lds_rgbh[threadIdx.x] = make_float4(cs.x, cs.y, cs.z, out.hit ? 1.0f : 0.0f);
+  if (k == 0 && pix_on) {
+    if (P.aux_hit_id) P.aux_hit_id[pix] = out.id;
+    if (P.aux_hit_t && out.id >= 0) P.aux_hit_t[pix] = out.t;
+  }
+  __syncthreads();
+  bool wrote = false;
+  if (k == 0 && pix_on) {
+    const float4* s = lds_rgbh + slot * n_samples;
+    V3 color;
+    bool any = false;
+    if (!aa) {
+      color = mk(s[0].x, s[0].y, s[0].z);
+      any = s[0].w != 0.0f;
+    } else {
+      V3 first[8], rest[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) first[l] = rest[l] = mk(0, 0, 0);
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        if ((uint32_t)l < n_samples && s[l].w != 0.0f) {
+          first[l] = mk(s[l].x, s[l].y, s[l].z);
+          any = true;
+        }
+      }
+      for (uint32_t base = 8; base < n_samples; base += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          uint32_t q = base + (uint32_t)l;
+          if (q < n_samples && s[q].w != 0.0f) {
+            rest[l] = mk(s[q].x, s[q].y, s[q].z) + rest[l];
+            any = true;
+          }
+        }
+      }
+      V3 lane8[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) lane8[l] = rest[l] + first[l];
+      color = ((lane8[0] + lane8[4]) + (lane8[2] + lane8[6])) + ((lane8[1] + lane8[5]) + (lane8[3] + lane8[7]));
+    }
+    if (any) {
+      wrote = true;
+      if (P.acc) {
+        // secondary rays are streaming: the pixel is resolved by rt_resolve_kernel
+        acc_add(P, pix, color);
+        P.acc[4 * (size_t)pix + 3] = 1;
+      } else {
+        P.argb[pix] = pack_argb(color);
+        if (P.aux_rgb) {
+          P.aux_rgb[3 * (size_t)pix + 0] = color.x;
+          P.aux_rgb[3 * (size_t)pix + 1] = color.y;
+          P.aux_rgb[3 * (size_t)pix + 2] = color.z;
+        }
+      }
+    }
+  }
+  wave_flush(wv, P, (unsigned long long)__popcll(__ballot(wrote)));
+}
+
+__global__ __launch_bounds__(256) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ uint32_t lds_stack[RT_WAVES_PER_BLOCK * RT_STACK_DEPTH];
+  __shared__ float4 lds_rgbh[256];
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    primary_body<true>(sc, P, lds_stack, lds_rgbh);
+  else
+    primary_body<false>(sc, P, lds_stack, lds_rgbh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// secondary kernel: one thread per queued ray (reflection / refraction child of any depth)
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack) {
+  Wave wv;
+  wave_init(wv, lds_stack);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool have = i < P.q_in_count;
+  RayIn r;
+  r.o = mk(0, 0, 0);
+  r.d_raw = mk(0, 0, 1);
+  r.n_start = 1.0f;
+  r.Wt = mk(0, 0, 0);
+  r.depth = 1;
+  r.kind = KIND_REFL;
+  r.pix = 0;
+  if (have) {
+    const size_t j = (size_t)P.q_in_first + i;
+    float4 a = P.q_in[0 * (size_t)P.q_capacity + j];
+    float4 b = P.q_in[1 * (size_t)P.q_capacity + j];
+    float4 c = P.q_in[2 * (size_t)P.q_capacity + j];
+    r.o = mk(a.x, a.y, a.z);
+    r.n_start = a.w;
+    r.d_raw = mk(b.x, b.y, b.z);
+    int dk = __float_as_int(b.w);
+    r.depth = dk >> 2;
+    r.kind = dk & 3;
+    r.Wt = mk(c.x, c.y, c.z);
+    r.pix = __float_as_uint(c.w);
+  }
+  RayOut out = process_ray<CULL>(sc, P, wv, have, r);
+  if (out.hit) acc_add(P, r.pix, out.contrib);
+  wave_flush(wv, P, 0ull);
+}
+
+__global__ __launch_bounds__(256) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ uint32_t lds_stack[RT_WAVES_PER_BLOCK * RT_STACK_DEPTH];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    render_body<true>(sc, P, lds_stack);
+    secondary_body<true>(sc, P, lds_stack);
   else
-    render_body<false>(sc, P, lds_stack);
+    secondary_body<false>(sc, P, lds_stack);
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve: fixed-point accumulator -> packed pixel (and clears the accumulator for the next frame)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= P.win_w * P.win_h) return;
+  const uint32_t gx = P.win_x0 + i % P.win_w, gy = P.win_y0 + i / P.win_w;
+  const uint32_t pix = gy * P.width + gx;
+  long long* a = P.acc + 4 * (size_t)pix;
+  long long r = a[0], g = a[1], b = a[2], f = a[3];
+  unsigned long long wrote = 0;
+  if (f) {
+    V3 c = mk((float)r * RT_ACC_INV_SCALE, (float)g * RT_ACC_INV_SCALE, (float)b * RT_ACC_INV_SCALE);
+    P.argb[pix] = pack_argb(c);
+    if (P.aux_rgb) {
+      P.aux_rgb[3 * (size_t)pix + 0] = c.x;
+      P.aux_rgb[3 * (size_t)pix + 1] = c.y;
+      P.aux_rgb[3 * (size_t)pix + 2] = c.z;
+    }
+    a[0] = a[1] = a[2] = a[3] = 0;
+    wrote = 1;
+  }
+  (void)wrote;
 }
 
 }  // namespace
 
-int rt_launch_render(const RtDevScene& sc, const RtDevParams& p, void* stream) {
-  uint32_t bx = (p.win_w + RT_BLOCK_W - 1) / RT_BLOCK_W;
-  uint32_t by = (p.win_h + RT_BLOCK_H - 1) / RT_BLOCK_H;
-  dim3 grid(bx * by), block(256);
-  hipLaunchKernelGGL(rt_render_kernel, grid, block, 0, (hipStream_t)stream, sc, p);
+// ---- host-side launchers ---------------------------------------------------------------------------
+uint32_t rt_primary_pixels_per_wg(const RtDevParams& p) {
+  const bool aa = (p.flags & RT_FLAG_ANTI_ALIASING) && p.aa_rays > 0;
+  return 256u / (aa ? p.aa_rays : 1u);
+}
+
+uint32_t rt_primary_total_wgs(const RtDevParams& p) {
+  uint32_t st_x = (p.win_w + 15u) / 16u, st_y = (p.win_h + 15u) / 16u;
+  uint64_t lin = (uint64_t)st_x * st_y * 256u;
+  uint32_t ppw = rt_primary_pixels_per_wg(p);
+  return (uint32_t)((lin + ppw - 1) / ppw);
+}
+
+int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_secondary(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+  uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
+  if (n_wgs == 0) return 0;
+  hipLaunchKernelGGL(rt_secondary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_resolve(const RtDevParams& p, void* stream) {
+  uint32_t n = p.win_w * p.win_h;
+  hipLaunchKernelGGL(rt_resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }

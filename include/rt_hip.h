@@ -158,6 +158,17 @@ typedef struct rt_stats {
   uint64_t pixels_written;
   double kernel_ms; /* device time of the render kernel(s) (CPU oracle: wall time) */
   double total_ms;  /* wall time of the call incl. copies */
+  /* GPU only (0 from the CPU oracle): SIMD efficiency of the ray loop.  wave_ray_passes = number of
+   * wavefront-level trips through cast_ray + shading; wave_ray_lanes = live lanes summed over those
+   * trips.  lanes / (64 * passes) = fraction of the 64-wide machine doing useful ray work. */
+  uint64_t wave_ray_passes;
+  uint64_t wave_ray_lanes;
+  /* GPU only: wavefront-level BVH work (one count per wave, not per lane) */
+  uint64_t wave_nearest_nodes; /* BVH nodes fetched by nearest-hit traversals */
+  uint64_t wave_nearest_tris;  /* triangle records tested by nearest-hit traversals */
+  uint64_t wave_shadow_nodes;  /* same for shadow rays */
+  uint64_t wave_shadow_tris;
+  uint64_t wave_shadow_passes; /* wavefront-level shadow-ray traversals */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */
@@ -217,8 +228,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 int rt_render(rt_scene* scene, const rt_params* params, uint32_t* argb, const rt_aux* aux,
               rt_stats* stats);
 
-/* Same, but `argb_dev` (and aux pointers) are DEVICE pointers on the scene's device and the
- * launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  stats (if not
+/* Same, but `argb_dev` (and aux pointers) are DEVICE pointers on the scene's device and all work
+ * is enqueued on `hip_stream` (a hipStream_t, NULL = default stream).  Without reflections /
+ * refractions this is one asynchronous kernel launch; with them the call drives the ray-streaming
+ * passes and returns when the last pass has been enqueued (it synchronises the stream in between to
+ * read queue sizes).  stats (if not
  * NULL) is filled with ray counters only after the caller synchronises AND calls
  * rt_render_collect_stats. */
 int rt_render_device(rt_scene* scene, const rt_params* params, uint32_t* argb_dev,

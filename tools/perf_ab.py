@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Quick kernel timing for A/B work (not the official metric): renders named workloads (optionally a
+window) through rt_render_device with HBM-resident buffers and prints kernel ms + ray rates.
+Usage: perf_ab.py [c3|c4|c2|default][:x0,y0,w,h] ... [--reps N]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, _abi, _lib, scenes
+from hslu_i.ba_raytracing.f2501_raytracer_amd.config import DEFAULT_FEATURES
+from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+
+reps = 3
+args = [a for a in sys.argv[1:]]
+if "--reps" in args:
+    i = args.index("--reps")
+    reps = int(args[i + 1])
+    del args[i:i + 2]
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+for spec in args or ["c3"]:
+    name, _, win = spec.partition(":")
+    window = tuple(int(v) for v in win.split(",")) if win else None
+    if name.startswith("sem="):
+        # sem=feat+feat[/depth][/model]  e.g. sem=high_resolution+realistic+high_quality/8/text
+        parts = name[4:].split("/")
+        kw = {}
+        if len(parts) > 1 and parts[1]:
+            kw["depth_override"] = int(parts[1])
+        cfg = RenderConfig.from_features(parts[0].split("+"), **kw)
+        flat = scenes.semesterbild(cfg, parts[2] if len(parts) > 2 else None).flatten()
+    elif name == "default":
+        cfg = RenderConfig.from_features(DEFAULT_FEATURES)
+        flat = scenes.semesterbild(cfg).flatten()
+    else:
+        cfg, flat, _ = bench.build_workload(name)
+    ds = DeviceScene(flat, 0)
+    p, keep = _abi.make_params(cfg, window=window)
+    fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
+    times = []
+    for r in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None, None))
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0:
+            times.append(e0.elapsed_time(e1))
+    st = _abi.rt_stats()
+    _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
+    rays = st.rays_primary + st.rays_reflection + st.rays_refraction
+    ms = float(np.median(times))
+    print(f"{spec:28s} kernel {ms:10.3f} ms  (min {min(times):.3f})  rays {rays:>11d}  shadow {st.rays_shadow:>13d}  "
+          f"simd_eff {st.wave_ray_lanes/max(1, 64*st.wave_ray_passes):.3f}  {rays/ms/1e3:8.1f} Mray/s  {st.rays_shadow/ms/1e6:7.2f} Gshadow/s  checksum {int(fb.to(torch.int64).sum()) & 0xFFFFFFFF:08x}")
+    sp = max(1, st.wave_shadow_passes)
+    print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
+          f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f}")
+    ds.close()
