@@ -55,6 +55,7 @@ class rt_stats(C.Structure):
         ("wave_ray_passes", C.c_uint64), ("wave_ray_lanes", C.c_uint64),
         ("wave_nearest_nodes", C.c_uint64), ("wave_nearest_tris", C.c_uint64),
         ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
+        ("wave_nearest_tris_exact", C.c_uint64), ("wave_shadow_tris_exact", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -8,7 +8,8 @@ import os
 from ._abi import rt_aux, rt_bvh_info, rt_params, rt_scene_desc, rt_stats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIB selects a diagnostic build of the same library (tools/, A/B timing); default: in-tree
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 EXPORTS = (
     "rt_device_count", "rt_scene_create", "rt_render", "rt_render_device", "rt_render_collect_stats",
     "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info",

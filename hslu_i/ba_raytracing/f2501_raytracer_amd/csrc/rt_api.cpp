@@ -432,6 +432,8 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   st->wave_shadow_nodes = c[9];
   st->wave_shadow_tris = c[10];
   st->wave_shadow_passes = c[11];
+  st->wave_nearest_tris_exact = c[12];
+  st->wave_shadow_tris_exact = c[13];
   return RT_OK;
 }
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rt_internal.h"
@@ -43,9 +44,10 @@ struct Aabb {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kMaxLeaf = 4;
-constexpr float kTraversalCost = 1.0f;
-constexpr float kTriCost = 2.0f;
+// tunables (environment overrides are for experiments only: RT_BVH_MAX_LEAF, RT_BVH_TRI_COST)
+uint32_t kMaxLeaf = 4;
+float kTraversalCost = 1.0f;
+float kTriCost = 2.0f;
 
 struct Builder {
   const std::vector<Aabb>& tb;      // per-triangle padded bounds
@@ -74,7 +76,7 @@ struct Builder {
       max_leaf = std::max(max_leaf, count);
       return me;
     };
-    if (count <= 2) return make_leaf();
+    if (count <= 1 || (count <= 2 && kMaxLeaf >= 2)) return make_leaf();
 
     // centroid bounds
     Aabb cb;
@@ -171,6 +173,8 @@ struct Builder {
 }  // namespace
 
 void rt_build_bvh(const float* v1, const float* e1, const float* e2, uint32_t n, RtBvh* out) {
+  if (const char* e = getenv("RT_BVH_MAX_LEAF")) kMaxLeaf = (uint32_t)atoi(e) < 1 ? 1u : (uint32_t)atoi(e);
+  if (const char* e = getenv("RT_BVH_TRI_COST")) kTriCost = (float)atof(e);
   out->nodes.clear();
   out->tri_order.resize(n);
   for (uint32_t i = 0; i < n; i++) out->tri_order[i] = i;

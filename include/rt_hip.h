@@ -169,6 +169,8 @@ typedef struct rt_stats {
   uint64_t wave_shadow_nodes;  /* same for shadow rays */
   uint64_t wave_shadow_tris;
   uint64_t wave_shadow_passes; /* wavefront-level shadow-ray traversals */
+  uint64_t wave_nearest_tris_exact; /* triangle tests that passed the conservative pre-filter */
+  uint64_t wave_shadow_tris_exact;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */

@@ -207,3 +207,17 @@ def test_default_features_match_reference_output_png_statistically():
     iou = float(((box.sum(2) > 1) & (ref.sum(2) > 1)).sum() / ((box.sum(2) > 1) | (ref.sum(2) > 1)).sum())
     print(f"vs output.png (4x4 box): mean abs {d.mean():.3f}/255, PSNR {psnr:.1f} dB, silhouette IoU {iou:.5f}")
     assert d.mean() < 1.0 and psnr > 38.0 and iou > 0.995
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5])
+def test_tiny_triangle_counts_single_leaf_bvh(n_tris):
+    """BVH edge cases: a scene whose whole triangle set is one leaf (root with an empty second child),
+    with spheres, shadows and transmissive triangles."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import FlatScene
+    cfg = RenderConfig.from_features(["reflections", "refractions"], width_override=96, height_override=80)
+    full = scenes.test_scene(cfg).flatten()
+    keep = [0, 1, 2, 40, 60][:n_tris]
+    flat = FlatScene(full.sphere_center, full.sphere_r_sq, full.sphere_r_inv, full.sphere_material,
+                     full.tri_v1[keep], full.tri_e1[keep], full.tri_e2[keep], full.tri_normal[keep],
+                     full.tri_material[keep], full.materials, full.lights)
+    compare(cfg, flat, None)

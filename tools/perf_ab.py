@@ -59,5 +59,5 @@ for spec in args or ["c3"]:
           f"simd_eff {st.wave_ray_lanes/max(1, 64*st.wave_ray_passes):.3f}  {rays/ms/1e3:8.1f} Mray/s  {st.rays_shadow/ms/1e6:7.2f} Gshadow/s  checksum {int(fb.to(torch.int64).sum()) & 0xFFFFFFFF:08x}")
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
-          f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f}")
+          f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
     ds.close()

@@ -16,14 +16,14 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
-kern = [r for r in rows if "rt_render_kernel" in r["Name"]][0]
+kern = [r for r in rows if "rt_primary_kernel" in r["Name"]][0]
 avg_ms = float(kern["AverageNs"]) / 1e6
 pmc = collections.OrderedDict()
 meta = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "rt_render_kernel" in r["Kernel_Name"]:
+        if "rt_primary_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
@@ -32,7 +32,7 @@ with open(os.path.join("profiles", f"{tag}_pmc.csv"), "w") as fh:
     fh.write("counter,mean_per_dispatch\n")
     for k, v in pmc.items():
         fh.write(f"{k},{v:.6g}\n")
-out = [f"# rocprofv3 summary {tag}: rt_render_kernel", "",
+out = [f"# rocprofv3 summary {tag}: rt_primary_kernel", "",
        f"* calls {kern['Calls']}, average {avg_ms:.3f} ms (min {float(kern['MinNs'])/1e6:.3f}, max {float(kern['MaxNs'])/1e6:.3f}), {kern['Percentage']} % of GPU time",
        f"* launch: {meta}"]
 if "FETCH_SIZE" in pmc:
