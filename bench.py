@@ -41,6 +41,9 @@ WORKLOADS = {
     # configs[3]
     "c4": dict(features=["high_resolution", "realistic", "extreme_quality"], model="text", scene="semesterbild",
                depth=8, name="semesterbild@high_resolution+realistic+extreme_quality depth 8 (text.obj)"),
+    # configs[4]: as c4 at 4K (the scene is aspect dependent, lib.rs:73-79)
+    "c5": dict(features=["realistic", "extreme_quality"], model="text", scene="semesterbild", depth=8, size=(3840, 2160),
+               name="semesterbild@3840x2160+realistic+extreme_quality depth 8 (text.obj)"),
 }
 
 
@@ -48,12 +51,30 @@ def build_workload(key):
     from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, scenes
 
     w = WORKLOADS[key]
-    cfg = RenderConfig.from_features(w["features"], depth_override=w.get("depth"))
+    size = w.get("size", (None, None))
+    cfg = RenderConfig.from_features(w["features"], depth_override=w.get("depth"), width_override=size[0],
+                                     height_override=size[1])
     if w["scene"] == "semesterbild":
         flat = scenes.semesterbild(cfg, w["model"]).flatten()
     else:
         flat = scenes.test_scene(cfg).flatten().without_triangles()
     return cfg, flat, w["name"]
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.csv, written by tools/summarize_profile.py from separate --pmc passes of this very
+    command): FETCH_SIZE (KiB) x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE (KiB)."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
+    if not files:
+        return None, None
+    vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(files[-1]))}
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0, os.path.basename(files[-1])
 
 
 def cpu_baseline(cfg, flat, budget_s=20.0):
@@ -63,14 +84,17 @@ def cpu_baseline(cfg, flat, budget_s=20.0):
     import oracle_lib
 
     threads = os.cpu_count() or 1
-    # probe a tiny window to size the sample for ~budget_s
-    cx, cy = cfg.width // 2 - 8, cfg.height // 2 - 8
+    # probe one pixel per thread to size the sample for ~budget_s of wall time on all host threads
+    side = max(4, int(np.ceil(np.sqrt(threads))))
+    cx, cy = cfg.width // 2 - side // 2, cfg.height // 2 - side // 2
     t0 = time.time()
-    _, _, st = oracle_lib.render(flat, cfg, window=(cx, cy, 16, 4), n_threads=threads, aux=False)
+    oracle_lib.render(flat, cfg, window=(cx, cy, side, side), n_threads=threads, aux=False)
     dt = max(time.time() - t0, 1e-3)
-    px_per_s = 64 / dt
-    rows = int(max(4, min(64, budget_s * px_per_s / 64)))
-    win = (cfg.width // 2 - 32, cfg.height // 2 - rows // 2, 64, rows)
+    px_per_s = side * side / dt
+    n_px = float(np.clip(budget_s * px_per_s, 256, 65536))
+    w = int(min(256, max(16, np.sqrt(n_px))))
+    h = int(max(16, min(256, n_px / w)))
+    win = (cfg.width // 2 - w // 2, cfg.height // 2 - h // 2, w, h)
     t0 = time.time()
     _, _, st = oracle_lib.render(flat, cfg, window=win, n_threads=threads, aux=False)
     dt = time.time() - t0
@@ -90,6 +114,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -107,10 +133,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg, flat, wname = build_workload(args.workload)
     lib = _lib.load()
@@ -119,7 +149,7 @@ def main():
     npix = cfg.width * cfg.height
     fb = torch.zeros(npix, dtype=torch.int32, device=dev)
     stream = torch.cuda.Stream(device=dev)
-    gather = TileGather(cfg, world, rank, dev) if world > 1 else None
+    gather = TileGather(cfg, world, rank, dev, host_staging=(args.backend == "gloo")) if world > 1 else None
 
     def frame(ev0=None, ev1=None):
         with torch.cuda.stream(stream):
@@ -155,6 +185,8 @@ def main():
                            st.pixels_written], dtype=torch.int64, device=dev)
     tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
+        if args.backend == "gloo":
+            counts, tmax = counts.cpu(), tmax.cpu()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     counts = counts.tolist()
@@ -183,8 +215,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "rt_render_kernel", "kernel_ms": kernel_ms,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_bytes()[0] if (args.workload == "c3" and world == 1) else None,
+                "traffic_source": pmc_traffic_bytes()[1] if (args.workload == "c3" and world == 1) else None,
+                "kernel": "rt_primary_kernel", "kernel_ms": kernel_ms,
                 "note": "algorithmic 64 B/ray ray-stream model (SURVEY 8d); the kernel is VALU/latency bound, "
                         "see DESIGN.md and profiles/",
             },

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -306,7 +307,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->aux_hit_id = aux_dev->hit_id;
     P->aux_hit_t = aux_dev->hit_t;
   }
-  P->counters = (unsigned long long*)s->counters.p;
+  P->counters = getenv("RT_NO_COUNTERS") ? nullptr : (unsigned long long*)s->counters.p;  // env: experiment only
   HIP_TRY(hipMemsetAsync(s->counters.p, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
 
   const bool aa_on = P->aa_rays > 0;

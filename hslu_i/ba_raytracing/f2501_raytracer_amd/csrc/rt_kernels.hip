@@ -13,23 +13,25 @@
 //   pixel pack              src/output/window.rs:105-109
 //
 // Execution model (MI355X-first, nothing like the reference's rayon + 8-lane packets):
-//   * one thread per pixel, one 64-lane wavefront per 8x8 pixel tile, 4 waves per workgroup
-//     (16x16 pixels), AA samples iterated inside the thread;
+//   * every ray is an independent work item.  rt_primary_kernel: one thread per (pixel, AA sample),
+//     a wavefront = the samples of a few adjacent pixels; rt_secondary_kernel: one thread per queued
+//     reflection / refraction ray.  Children are appended to per-level ray queues in HBM (SoA float4
+//     planes, one atomic per wavefront) that the host drains deepest level first; pixel sums of
+//     secondary rays use 64-bit fixed-point atomics (order independent, bit-reproducible);
 //   * BVH traversal is WAVE-COOPERATIVE: the 64 rays of a wavefront walk the tree together.  The
-//     current node index is wave-uniform, so node and triangle records are fetched once per wave
-//     (uniform address -> scalar/broadcast loads) and the traversal stack is ONE stack per
-//     wavefront kept in LDS, driven by __ballot votes; lanes whose ray misses a box are masked
-//     for that subtree.  Coherent rays (camera rays of a tile, shadow rays of neighbouring hit
-//     points towards one light) make the union of visited nodes close to the per-ray set;
-//   * the Whitted recursion is an explicit per-thread ray stack in HBM (SoA, coalesced), each
-//     entry carrying its RGB path weight; contributions are linear in the child colour so the
-//     sum over the tree equals the recursion up to fp reassociation;
+//     current node index is wave-uniform, node / triangle / sphere / light records are fetched with
+//     scalar loads (constant address space -> s_load_dwordx4/x16), and the traversal stack is ONE
+//     stack per wavefront kept in LDS, driven by __ballot votes; lanes whose ray misses a box are
+//     masked for that subtree;
+//   * a conservative, staged triangle pre-filter keeps the IEEE division of the literal test for
+//     the few triangles some lane can actually hit;
 //   * no MFMA: this is branchy fp32 intersection math, not a contraction.
 //
 // Numerics: compiled with -ffp-contract=off; fused multiply-adds appear exactly where the
 // reference calls mul_add (written __builtin_fmaf).  Division and sqrt are the correctly rounded
-// forms (hipcc default), so every hit/miss decision and every t is bit-identical to the CPU
-// restatement in oracle/; only tanhf/powf differ in the last ulps.
+// forms (hipcc default) wherever a hit / occlusion / spawn decision depends on them, so every such
+// decision and every t is bit-identical to the CPU restatement in oracle/; colour-only factors use
+// v_rcp/v_rsq (1 ulp), tanhf/powf are ocml's.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -622,20 +624,20 @@ __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, 
     // RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
     // critical path (hundreds of thousands of wavefronts retire per frame); the host sums them
     unsigned long long* c = P.counters + (size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u;
-    atomicAdd(&c[0], w.cnt_kind[0]);
-    atomicAdd(&c[1], w.cnt_kind[1]);
-    atomicAdd(&c[2], w.cnt_kind[2]);
-    atomicAdd(&c[3], w.cnt_shadow);
+    if (w.cnt_kind[0]) atomicAdd(&c[0], w.cnt_kind[0]);
+    if (w.cnt_kind[1]) atomicAdd(&c[1], w.cnt_kind[1]);
+    if (w.cnt_kind[2]) atomicAdd(&c[2], w.cnt_kind[2]);
+    if (w.cnt_shadow) atomicAdd(&c[3], w.cnt_shadow);
     if (written) atomicAdd(&c[4], written);
-    atomicAdd(&c[5], w.cnt_pass);
-    atomicAdd(&c[6], w.cnt_lanes);
-    atomicAdd(&c[7], w.ctx.n_nodes);
-    atomicAdd(&c[8], w.ctx.n_tris);
-    atomicAdd(&c[9], w.ctx.s_nodes);
-    atomicAdd(&c[10], w.ctx.s_tris);
-    atomicAdd(&c[11], w.ctx.s_passes);
-    atomicAdd(&c[12], w.ctx.n_exact);
-    atomicAdd(&c[13], w.ctx.s_exact);
+    if (w.cnt_pass) atomicAdd(&c[5], w.cnt_pass);
+    if (w.cnt_lanes) atomicAdd(&c[6], w.cnt_lanes);
+    if (w.ctx.n_nodes) atomicAdd(&c[7], w.ctx.n_nodes);
+    if (w.ctx.n_tris) atomicAdd(&c[8], w.ctx.n_tris);
+    if (w.ctx.s_nodes) atomicAdd(&c[9], w.ctx.s_nodes);
+    if (w.ctx.s_tris) atomicAdd(&c[10], w.ctx.s_tris);
+    if (w.ctx.s_passes) atomicAdd(&c[11], w.ctx.s_passes);
+    if (w.ctx.n_exact) atomicAdd(&c[12], w.ctx.n_exact);
+    if (w.ctx.s_exact) atomicAdd(&c[13], w.ctx.s_exact);
   }
 }
 

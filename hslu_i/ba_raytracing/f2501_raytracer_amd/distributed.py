@@ -51,10 +51,13 @@ def owned_pixel_indices(cfg: RenderConfig, n_ranks: int, rank: int) -> np.ndarra
 class TileGather:
     """Gathers every rank's owned pixels into rank 0's full framebuffer (int32 view of 0xAARRGGBB)."""
 
-    def __init__(self, cfg: RenderConfig, world: int, rank: int, device):
+    def __init__(self, cfg: RenderConfig, world: int, rank: int, device, host_staging: bool = False):
         import torch
 
         self.world, self.rank = world, rank
+        self.host_staging = host_staging  # rehearsal only: move the payload through gloo on the host
+        self.device = device
+        comm_device = torch.device("cpu") if host_staging else device
         idx = [owned_pixel_indices(cfg, world, r) for r in range(world)]
         self.counts = [int(i.shape[0]) for i in idx]
         self.max_len = max(self.counts)
@@ -63,7 +66,7 @@ class TileGather:
         self.recv: List = []
         self.all_idx: List = []
         if rank == 0:
-            self.recv = [torch.zeros(self.max_len, dtype=torch.int32, device=device) for _ in range(world)]
+            self.recv = [torch.zeros(self.max_len, dtype=torch.int32, device=comm_device) for _ in range(world)]
             self.all_idx = [torch.from_numpy(i).to(device) for i in idx]
 
     def run(self, fb, stream=None):
@@ -72,8 +75,9 @@ class TileGather:
 
         n = self.counts[self.rank]
         torch.index_select(fb, 0, self.own_idx, out=self.send[:n])
-        dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+        send = self.send.cpu() if self.host_staging else self.send
+        dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
         if self.rank == 0:
             for r in range(1, self.world):
-                fb.index_copy_(0, self.all_idx[r], self.recv[r][: self.counts[r]])
+                fb.index_copy_(0, self.all_idx[r], self.recv[r][: self.counts[r]].to(self.device))
         return fb

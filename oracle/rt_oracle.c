@@ -577,7 +577,7 @@ typedef struct {
   const rt_params* p;
   uint32_t* argb;
   const rt_aux* aux;
-  uint32_t x0, y0, w, h;
+  uint32_t x0, y0, w, h, chunk;
   volatile uint32_t* next_row;
   uint64_t rays[3], shadow, written;
 } job_t;
@@ -587,8 +587,6 @@ static int tile_owned(const rt_params* P, uint32_t gx, uint32_t gy) {
   uint32_t ts = P->tile_size ? P->tile_size : 48u;
   return rt_tile_owner(gx / ts, gy / ts, P->n_ranks) == P->rank;
 }
-
-#define RT_CHUNK 8u
 
 static void* worker(void* arg) {
   job_t* j = (job_t*)arg;
@@ -605,10 +603,11 @@ static void* worker(void* arg) {
   /* work items: runs of RT_CHUNK pixels in row-major window order (fine-grained so that small
    * windows still spread over all threads) */
   const uint32_t total = j->w * j->h;
+  const uint32_t chunk = j->chunk;
   for (;;) {
-    uint32_t first = __atomic_fetch_add(j->next_row, RT_CHUNK, __ATOMIC_RELAXED);
+    uint32_t first = __atomic_fetch_add(j->next_row, chunk, __ATOMIC_RELAXED);
     if (first >= total) break;
-    uint32_t last = first + RT_CHUNK < total ? first + RT_CHUNK : total;
+    uint32_t last = first + chunk < total ? first + chunk : total;
     for (uint32_t k = first; k < last; k++) {
       uint32_t gx = j->x0 + k % j->w, gy = j->y0 + k / j->w;
       if (!tile_owned(j->p, gx, gy)) continue;
@@ -666,6 +665,8 @@ int rt_cpu_render(const rt_scene_desc* desc, const rt_params* params, uint32_t* 
     jobs[i].w = w;
     jobs[i].h = h;
     jobs[i].next_row = &next_row;
+    /* runs of pixels small enough that every thread gets >= 8 work items */
+    jobs[i].chunk = (w * h) / ((uint32_t)n_threads * 8u) < 1u ? 1u : ((w * h) / ((uint32_t)n_threads * 8u) > 8u ? 8u : (w * h) / ((uint32_t)n_threads * 8u));
   }
   if (n_threads == 1) {
     worker(&jobs[0]);
