@@ -65,7 +65,7 @@ class rt_stats(C.Structure):
 class rt_bvh_info(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf_size", C.c_uint32),
-        ("bytes_nodes", C.c_uint64), ("bytes_triangles", C.c_uint64),
+        ("bytes_nodes", C.c_uint64), ("bytes_triangles", C.c_uint64), ("n_references", C.c_uint32),
     ]
 
 

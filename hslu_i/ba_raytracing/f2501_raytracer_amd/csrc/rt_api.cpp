@@ -149,12 +149,30 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if ((rc = upload(s->sphere_mat, d->sphere_material, (size_t)ns * 4)) != RT_OK) return bail(rc);
   }
   RtBvh bvh;
-  rt_build_bvh(d->tri_v1, d->tri_e1, d->tri_e2, nt, &bvh);
   {
-    // leaf-order intersection records; shading records twice: [0,nt) leaf order, [nt,2nt) canonical
-    std::vector<float> isect(12 * (size_t)nt), shade(8 * (size_t)nt);
-    for (uint32_t slot = 0; slot < nt; slot++) {
-      uint32_t t = bvh.tri_order[slot];
+    // transmissive triangles must be referenced exactly once (their shadow contributions add up)
+    std::vector<uint8_t> no_split(nt, 0);
+    for (uint32_t i = 0; i < nt; i++) {
+      const float* r = d->materials + (size_t)d->tri_material[i] * RT_MATERIAL_STRIDE;
+      no_split[i] = (r[RT_MAT_HAS_OPACITY] != 0.0f && !(std::fabs(r[RT_MAT_OPACITY]) <= 1.1920929e-7f)) ? 1 : 0;
+    }
+    rt_build_bvh(d->tri_v1, d->tri_e1, d->tri_e2, no_split.data(), nt, &bvh);
+  }
+  const uint32_t n_slots = (uint32_t)bvh.tri_order.size();
+  {
+    // leaf-order intersection records; shading records: [0,n_slots) leaf order, then canonical order
+    std::vector<float> isect(12 * (size_t)n_slots), shade(4 * ((size_t)n_slots + nt));
+    auto put_shade = [&](size_t dst, uint32_t t) {
+      float* sh = &shade[4 * dst];
+      sh[0] = d->tri_normal[3 * (size_t)t + 0];
+      sh[1] = d->tri_normal[3 * (size_t)t + 1];
+      sh[2] = d->tri_normal[3 * (size_t)t + 2];
+      uint32_t m = d->tri_material[t];
+      memcpy(&sh[3], &m, 4);
+    };
+    for (uint32_t t = 0; t < nt; t++) put_shade((size_t)n_slots + t, t);
+    for (uint32_t slot = 0; slot < n_slots; slot++) {
+      uint32_t t = bvh.tri_order[slot] & ~RT_TRI_DUPLICATE;
       const float* v1 = d->tri_v1 + 3 * (size_t)t;
       const float* e1 = d->tri_e1 + 3 * (size_t)t;
       const float* e2 = d->tri_e2 + 3 * (size_t)t;
@@ -168,19 +186,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       q[0] = v1[0], q[1] = v1[1], q[2] = v1[2], q[3] = e1[0];
       q[4] = e1[1], q[5] = e1[2], q[6] = e2[0], q[7] = e2[1];
       q[8] = e2[2], q[9] = X[0], q[10] = X[1], q[11] = X[2];
-      for (int pass = 0; pass < 2; pass++) {
-        size_t dst = pass == 0 ? (size_t)slot : (size_t)nt + t;
-        float* sh = &shade[4 * dst];
-        sh[0] = d->tri_normal[3 * (size_t)t + 0];
-        sh[1] = d->tri_normal[3 * (size_t)t + 1];
-        sh[2] = d->tri_normal[3 * (size_t)t + 2];
-        uint32_t m = d->tri_material[t];
-        memcpy(&sh[3], &m, 4);
-      }
+      put_shade(slot, t);
     }
     if ((rc = upload(s->tri_isect, isect.data(), isect.size() * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->tri_shade, shade.data(), shade.size() * 4)) != RT_OK) return bail(rc);
-    if ((rc = upload(s->tri_id, bvh.tri_order.data(), (size_t)nt * 4)) != RT_OK) return bail(rc);
+    if ((rc = upload(s->tri_id, bvh.tri_order.data(), (size_t)n_slots * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
   }
   {
@@ -214,6 +224,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
   s->dev.nodes = (const RtNode*)s->nodes.p;
   s->dev.n_spheres = ns;
   s->dev.n_triangles = nt;
+  s->dev.n_slots = n_slots;
   s->dev.n_lights = d->n_lights;
   s->dev.n_nodes = (uint32_t)bvh.nodes.size();
   s->info.n_nodes = (uint32_t)bvh.nodes.size();
@@ -221,7 +232,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
   s->info.max_depth = bvh.max_depth;
   s->info.max_leaf_size = bvh.max_leaf;
   s->info.bytes_nodes = bvh.nodes.size() * sizeof(RtNode);
-  s->info.bytes_triangles = (size_t)nt * (48 + 2 * 16 + 4);
+  s->info.bytes_triangles = (size_t)n_slots * (48 + 16 + 4) + (size_t)nt * 16;
+  s->info.n_references = n_slots;
   if (bvh.max_depth + 2 > 64) return bail(fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth));
   *out = s;
   return RT_OK;

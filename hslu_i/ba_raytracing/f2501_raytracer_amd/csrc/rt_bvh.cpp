@@ -48,6 +48,8 @@ constexpr int kBins = 16;
 uint32_t kMaxLeaf = 4;
 float kTraversalCost = 1.0f;
 float kTriCost = 2.0f;
+int kSplitDepth = 0;       // early split clipping: at most 2^depth references per triangle (0 = off: measured slower)
+float kSplitGain = 0.8f;   // split only if area(left) + area(right) < gain * area(whole)
 
 struct Builder {
   const std::vector<Aabb>& tb;      // per-triangle padded bounds
@@ -172,43 +174,154 @@ struct Builder {
 
 }  // namespace
 
-void rt_build_bvh(const float* v1, const float* e1, const float* e2, uint32_t n, RtBvh* out) {
+// ---- early split clipping -------------------------------------------------------------------------
+// The text mesh is full of slivers (median AABB area = 3.8x the triangle's, p90 8.3x): a wavefront
+// that enters such a box almost always misses the triangle.  Before the BVH is built, the REFERENCE
+// of a triangle whose box is loose is split at the midpoint of its longest axis (the triangle is
+// clipped against the plane, each half gets the box of its clipped polygon), recursively.  A
+// triangle may then be referenced from several leaves; the traversal tests the whole triangle with
+// the literal test whenever it meets one of its references.  That is result-neutral for nearest
+// hits (same t and id) and for opaque occluders (a lane stops at its first opaque hit), but NOT for
+// transmissive triangles, whose opacity/filter contributions must be counted once: those are never
+// split (`no_split`).
+namespace {
+
+struct Ref {
+  Aabb box;
+  uint32_t tri;
+};
+
+// clips polygon `in` (n points) against the half space  sign*(p[axis] - pos) <= 0
+int clip_poly(const float (*in)[3], int n, int axis, float pos, float sign, float (*out)[3]) {
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const float* a = in[i];
+    const float* b = in[(i + 1) % n];
+    float da = sign * (a[axis] - pos), db = sign * (b[axis] - pos);
+    if (da <= 0.f) {
+      for (int k = 0; k < 3; k++) out[m][k] = a[k];
+      m++;
+    }
+    if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+      float t = da / (da - db);
+      for (int k = 0; k < 3; k++) out[m][k] = a[k] + t * (b[k] - a[k]);
+      out[m][axis] = pos;
+      m++;
+    }
+  }
+  return m;
+}
+
+void split_refs(const float (*poly)[3], int n, const Aabb& bounds, uint32_t tri, int depth, float min_extent,
+                std::vector<Ref>& out) {
+  Aabb box;
+  box.reset();
+  for (int i = 0; i < n; i++) box.grow(poly[i]);
+  for (int a = 0; a < 3; a++) {  // never grow beyond the parent's bounds
+    box.lo[a] = std::max(box.lo[a], bounds.lo[a]);
+    box.hi[a] = std::min(box.hi[a], bounds.hi[a]);
+  }
+  int axis = 0;
+  float ext = 0.f;
+  for (int a = 0; a < 3; a++)
+    if (box.hi[a] - box.lo[a] > ext) {
+      ext = box.hi[a] - box.lo[a];
+      axis = a;
+    }
+  bool done = depth <= 0 || ext <= min_extent || n < 3;
+  if (!done) {
+    float pos = 0.5f * (box.lo[axis] + box.hi[axis]);
+    float l[10][3], r[10][3];
+    int nl = clip_poly(poly, n, axis, pos, 1.f, l);
+    int nr = clip_poly(poly, n, axis, pos, -1.f, r);
+    if (nl >= 3 && nr >= 3) {
+      Aabb bl, brr;
+      bl.reset();
+      brr.reset();
+      for (int i = 0; i < nl; i++) bl.grow(l[i]);
+      for (int i = 0; i < nr; i++) brr.grow(r[i]);
+      // split only when it pays: the two halves together are clearly smaller than the whole
+      if (bl.half_area() + brr.half_area() < kSplitGain * box.half_area()) {
+        Aabb bndl = box, bndr = box;
+        bndl.hi[axis] = pos;
+        bndr.lo[axis] = pos;
+        split_refs(l, nl, bndl, tri, depth - 1, min_extent, out);
+        split_refs(r, nr, bndr, tri, depth - 1, min_extent, out);
+        return;
+      }
+    }
+  }
+  Ref rf;
+  rf.box = box;
+  rf.tri = tri;
+  out.push_back(rf);
+}
+
+}  // namespace
+
+void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n, RtBvh* out) {
   if (const char* e = getenv("RT_BVH_MAX_LEAF")) kMaxLeaf = (uint32_t)atoi(e) < 1 ? 1u : (uint32_t)atoi(e);
   if (const char* e = getenv("RT_BVH_TRI_COST")) kTriCost = (float)atof(e);
+  if (const char* e = getenv("RT_BVH_SPLIT_DEPTH")) kSplitDepth = atoi(e);
+  if (const char* e = getenv("RT_BVH_SPLIT_GAIN")) kSplitGain = (float)atof(e);
   out->nodes.clear();
-  out->tri_order.resize(n);
-  for (uint32_t i = 0; i < n; i++) out->tri_order[i] = i;
+  out->tri_order.clear();
   out->n_leaves = out->max_depth = out->max_leaf = 0;
 
-  std::vector<Aabb> tb(n);
-  std::vector<float> cent(3 * (size_t)n);
+  // references (one or more per triangle)
+  std::vector<Ref> refs;
+  refs.reserve((size_t)n * 2);
+  // splitting stops at the median triangle extent: below that boxes are as tight as the typical one
+  float min_extent = 0.f;
+  if (n && kSplitDepth > 0) {
+    std::vector<float> exts(n);
+    for (uint32_t i = 0; i < n; i++) {
+      float m = 0.f;
+      for (int a = 0; a < 3; a++) {
+        float p0 = v1[3 * (size_t)i + a], p1 = p0 + e1[3 * (size_t)i + a], p2 = p0 + e2[3 * (size_t)i + a];
+        m = std::max(m, std::max(p0, std::max(p1, p2)) - std::min(p0, std::min(p1, p2)));
+      }
+      exts[i] = m;
+    }
+    std::nth_element(exts.begin(), exts.begin() + n / 2, exts.end());
+    min_extent = exts[n / 2];
+  }
   for (uint32_t i = 0; i < n; i++) {
-    float p0[3], p1[3], p2[3];
+    float poly[3][3];
     for (int a = 0; a < 3; a++) {
-      p0[a] = v1[3 * (size_t)i + a];
-      p1[a] = p0[a] + e1[3 * (size_t)i + a];
-      p2[a] = p0[a] + e2[3 * (size_t)i + a];
+      poly[0][a] = v1[3 * (size_t)i + a];
+      poly[1][a] = poly[0][a] + e1[3 * (size_t)i + a];
+      poly[2][a] = poly[0][a] + e2[3 * (size_t)i + a];
     }
     Aabb b;
     b.reset();
-    b.grow(p0);
-    b.grow(p1);
-    b.grow(p2);
+    for (int k = 0; k < 3; k++) b.grow(poly[k]);
+    bool split = kSplitDepth > 0 && !(no_split && no_split[i]);
+    size_t first = refs.size();
+    split_refs(poly, 3, b, i, split ? kSplitDepth : 0, min_extent, refs);
     // Padding: absolute 2e-5 plus 1e-4 of the triangle's largest extent plus 4 ulp of the
     // coordinate magnitude.  The literal test accepts u,v slightly outside [0,1] through rounding,
-    // and p1/p2 above are themselves rounded.
+    // p1/p2 above are themselves rounded, and clipped boxes carry the rounding of the clip.
     float ext = 0.f, mag = 0.f;
     for (int a = 0; a < 3; a++) {
       ext = std::max(ext, b.hi[a] - b.lo[a]);
       mag = std::max(mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
     }
     float pad = 2e-5f + 1e-4f * ext + 4.0f * 1.1920929e-7f * mag;
-    for (int a = 0; a < 3; a++) {
-      b.lo[a] -= pad;
-      b.hi[a] += pad;
-      cent[3 * (size_t)i + a] = (p0[a] + p1[a] + p2[a]) * (1.0f / 3.0f);
-    }
-    tb[i] = b;
+    for (size_t k = first; k < refs.size(); k++)
+      for (int a = 0; a < 3; a++) {
+        refs[k].box.lo[a] -= pad;
+        refs[k].box.hi[a] += pad;
+      }
+  }
+  const uint32_t nr = (uint32_t)refs.size();
+  std::vector<uint32_t> order(nr);
+  std::vector<Aabb> tb(nr);
+  std::vector<float> cent(3 * (size_t)nr);
+  for (uint32_t i = 0; i < nr; i++) {
+    order[i] = i;
+    tb[i] = refs[i].box;
+    for (int a = 0; a < 3; a++) cent[3 * (size_t)i + a] = 0.5f * (refs[i].box.lo[a] + refs[i].box.hi[a]);
   }
 
   RtNode root;
@@ -224,8 +337,8 @@ void rt_build_bvh(const float* v1, const float* e1, const float* e2, uint32_t n,
     return;
   }
 
-  Builder bld{tb, cent, out->tri_order, out->nodes};
-  Builder::Child top = bld.build(0, n, 1);
+  Builder bld{tb, cent, order, out->nodes};
+  Builder::Child top = bld.build(0, nr, 1);
   if (top.n != 0) {
     // the whole scene is a single leaf: wrap it in a root whose second child is empty
     for (int a = 0; a < 3; a++) {
@@ -240,4 +353,12 @@ void rt_build_bvh(const float* v1, const float* e1, const float* e2, uint32_t n,
   out->n_leaves = bld.n_leaves;
   out->max_depth = bld.max_depth;
   out->max_leaf = bld.max_leaf;
+  // leaf slot -> triangle; later references of a triangle (in slot order) carry RT_TRI_DUPLICATE
+  out->tri_order.resize(nr);
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t slot = 0; slot < nr; slot++) {
+    uint32_t t = refs[order[slot]].tri;
+    out->tri_order[slot] = t | (seen[t] ? RT_TRI_DUPLICATE : 0u);
+    seen[t] = 1;
+  }
 }

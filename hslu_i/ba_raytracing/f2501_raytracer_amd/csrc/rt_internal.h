@@ -12,10 +12,10 @@
 //
 // spheres      float4 {cx, cy, cz, r_sq}                      16 B / sphere
 // sphere_mat   uint32 material row
-// tri_isect    3 x float4 per triangle (BVH leaf order):      48 B / triangle
+// tri_isect    3 x float4 per triangle REFERENCE (BVH leaf order, n_slots entries):  48 B each
 //                {v1.xyz, e1.x} {e1.yz, e2.xy} {e2.z, x.xyz}   x = e1 x e2 (ray independent part of
 //                                                              Mat3::inversed, triangle.rs:174-177)
-// tri_shade    float4 {n.xyz, bits(material row)}  (BVH leaf order)   16 B / triangle
+// tri_shade    float4 {n.xyz, bits(material row)}: [0,n_slots) leaf order, then [n_slots, +n_triangles) canonical
 // tri_id       uint32 canonical triangle index (insertion order) of the triangle in leaf slot i
 // materials    3 x float4 per material: {r,g,b,metallic} {shininess, ior, opacity, boost}
 //                {has_opacity,0,0,0}
@@ -35,10 +35,11 @@ struct RtNode {
 static_assert(sizeof(RtNode) == 64, "node must be 64 bytes");
 
 #define RT_NODE_EMPTY 0xFFFFFFFFu  // c* value of an absent child (box is inverted, never hit)
+#define RT_TRI_DUPLICATE 0x80000000u  // tri_id flag: not the first reference of its triangle (slot order)
 
 struct RtBvh {
   std::vector<RtNode> nodes;        // nodes[0] is the root
-  std::vector<uint32_t> tri_order;  // leaf slot -> canonical triangle index
+  std::vector<uint32_t> tri_order;  // leaf slot -> canonical triangle index (| RT_TRI_DUPLICATE)
   uint32_t n_leaves = 0;
   uint32_t max_depth = 0;
   uint32_t max_leaf = 0;
@@ -46,7 +47,7 @@ struct RtBvh {
 
 // Builds a binned-SAH BVH2 over the triangles (v1, e1, e2 as in rt_scene_desc).  Boxes are padded
 // so that the fp32 slab test can never cull a triangle the literal intersection test accepts.
-void rt_build_bvh(const float* v1, const float* e1, const float* e2, uint32_t n, RtBvh* out);
+void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n, RtBvh* out);
 
 // ---- kernel argument block ---------------------------------------------------------------------
 struct RtDevScene {
@@ -59,6 +60,7 @@ struct RtDevScene {
   const float4* lights;
   const RtNode* nodes;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
+  uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
 };
 
 struct RtDevParams {

@@ -35,12 +35,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rt_internal.h"
 
 #define RT_EPS 1.1920929e-7f
-#define RT_WAVES_PER_BLOCK 4
-#define RT_STACK_DEPTH 64
+#define RT_STACK_DEPTH 64  /* one VGPR's worth of lanes */
 
 // Diagnostic builds only (make ABLATE=n): RT_DOUBLE bit i repeats one component's arithmetic with an
 // opaque copy of its inputs, so the time delta of the build IS that component's share of the kernel
@@ -290,23 +290,31 @@ __device__ __forceinline__ BoxRay box_ray(V3 o, V3 d) {
   return r;
 }
 
-// conservative slab test against a padded box (boxes are padded by rt_bvh.cpp, the slack below
-// covers the rounding of this test itself); tlimit_s = t limit with its slack already added
-__device__ __forceinline__ bool box_hit(const float* lo, const float* hi, const BoxRay& r, float tlimit_s,
-                                        float& tnear) {
+// Conservative slab test of BOTH child boxes of a node (boxes are padded by rt_bvh.cpp; the slack
+// below covers the rounding of this test itself).  tlimit_s = t limit with its slack already added.
+// Straight-line code, no short-circuit: predicates stay in SGPR lane masks.  (Picking near/far planes
+// by the packet's direction signs was tried: hipcc turns the uniform selects into v_mov + v_cndmask
+// triples, slower than the per-lane min/max form below.)
+__device__ __forceinline__ void box_one(const float* lo, const float* hi, const BoxRay& r, float& tmin, float& tmax) {
   float tx1 = __builtin_fmaf(lo[0], r.inv.x, r.noi.x), tx2 = __builtin_fmaf(hi[0], r.inv.x, r.noi.x);
   float ty1 = __builtin_fmaf(lo[1], r.inv.y, r.noi.y), ty2 = __builtin_fmaf(hi[1], r.inv.y, r.noi.y);
   float tz1 = __builtin_fmaf(lo[2], r.inv.z, r.noi.z), tz2 = __builtin_fmaf(hi[2], r.inv.z, r.noi.z);
-  float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-  float tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-  tnear = tmin;
-  float tmax_s = __builtin_fmaf(fabsf(tmax), 4e-6f, tmax + 1e-5f);
-  return (tmin <= fminf(tmax_s, tlimit_s)) && (tmax_s >= 0.0f);
+  tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+  tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+}
+__device__ __forceinline__ void box_pair(const RtNode& nd, const BoxRay& r, float tlimit_s, bool& h0, bool& h1,
+                                         float& tn0, float& tn1) {
+  float tm0, tm1;
+  box_one(nd.lo0, nd.hi0, r, tn0, tm0);
+  box_one(nd.lo1, nd.hi1, r, tn1, tm1);
+  float s0 = __builtin_fmaf(fabsf(tm0), 4e-6f, tm0 + 1e-5f);
+  float s1 = __builtin_fmaf(fabsf(tm1), 4e-6f, tm1 + 1e-5f);
+  h0 = (tn0 <= fminf(s0, tlimit_s)) & (s0 >= 0.0f);
+  h1 = (tn1 <= fminf(s1, tlimit_s)) & (s1 >= 0.0f);
 }
 __device__ __forceinline__ float t_limit_slack(float tlimit) {
   return __builtin_fmaf(fabsf(tlimit), 4e-6f, tlimit + 1e-5f);
 }
-
 struct Hit {
   float t;
   int id;  // canonical object index, -1 = none
@@ -331,7 +339,6 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
 }
 
 struct WaveCtx {
-  uint32_t* stack;  // this wavefront's traversal stack in LDS
   // wave-level work counters (uniform)
   unsigned long long n_nodes, n_tris, s_nodes, s_tris, s_passes, n_exact, s_exact;
 };
@@ -377,7 +384,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       }
     }
     if (__ballot(h)) {
-      int id = tri_base + (int)uload(&sc.tri_id[slot]);
+      int id = tri_base + (int)(uload(&sc.tri_id[slot]) & ~RT_TRI_DUPLICATE);
       if (h && (t < best.t || (t == best.t && id > best.id))) {
         best.t = t;
         best.id = id;
@@ -386,60 +393,69 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   };
 
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
-    for (uint32_t s = 0; s < sc.n_triangles; s++) test_tri(s, alive);
+    // the literal scan visits every triangle once: skip the extra references of split triangles
+    for (uint32_t s = 0; s < sc.n_slots; s++)
+      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, alive);
     return best;
   }
 
   const BoxRay br = box_ray(o, d);
-  uint32_t sp = 0;
-  uint32_t node = 0;
-  for (;;) {
-    const RtNode nd = uload(&sc.nodes[node]);
-    W.n_nodes++;
-    float tn0, tn1;
-    const float tl = t_limit_slack(best.t);
-    bool h0 = alive && (nd.c0 != RT_NODE_EMPTY) && box_hit(nd.lo0, nd.hi0, br, tl, tn0);
-    bool h1 = alive && (nd.c1 != RT_NODE_EMPTY) && box_hit(nd.lo1, nd.hi1, br, tl, tn1);
-    unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
-    uint32_t next = RT_NODE_EMPTY;
-    bool in0 = false, in1 = false;  // internal children to descend into
-    if (b0) {
-      if (nd.n0) {
-        W.n_tris += nd.n0;
-        for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
-      } else {
-        in0 = true;
+  const uint32_t lane_id = threadIdx.x & 63u;
+  // The traversal stack is ONE stack per wavefront, held in the 64 lanes of a single VGPR
+  // (push = select on lane id, pop = v_readlane with a scalar lane index): no LDS round trip.
+  const unsigned long long grp = __ballot(alive);
+  {
+    uint32_t stk = 0;
+    uint32_t sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+      const RtNode nd = uload(&sc.nodes[node]);
+      W.n_nodes++;
+      float tn0, tn1;
+      bool h0, h1;
+      box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
+      const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & grp) : 0ull;
+      const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & grp) : 0ull;
+      uint32_t next = RT_NODE_EMPTY;
+      bool in0 = false, in1 = false;  // internal children to descend into
+      if (b0) {
+        if (nd.n0) {
+          W.n_tris += nd.n0;
+          const bool on = (b0 >> lane_id) & 1ull;
+          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, on);
+        } else {
+          in0 = true;
+        }
       }
-    }
-    if (b1) {
-      if (nd.n1) {
-        W.n_tris += nd.n1;
-        for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
-      } else {
-        in1 = true;
+      if (b1) {
+        if (nd.n1) {
+          W.n_tris += nd.n1;
+          const bool on = (b1 >> lane_id) & 1ull;
+          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, on);
+        } else {
+          in1 = true;
+        }
       }
+      if (in0 && in1) {
+        // near-first by wave vote among lanes that hit both children
+        const unsigned long long both = b0 & b1;
+        const unsigned long long pref1 = __ballot(tn1 < tn0) & both;
+        const bool first1 = 2 * __popcll(pref1) > __popcll(both);
+        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;  // push: lane `sp` of the stack register
+        sp++;
+        next = first1 ? nd.c1 : nd.c0;
+      } else if (in0) {
+        next = nd.c0;
+      } else if (in1) {
+        next = nd.c1;
+      }
+      if (next == RT_NODE_EMPTY) {
+        if (sp == 0) break;
+        sp--;
+        next = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
+      }
+      node = next;
     }
-    if (in0 && in1) {
-      // near-first by wave vote among lanes that hit both children
-      unsigned long long both = b0 & b1;
-      unsigned long long pref1 = __ballot(h0 && h1 && (tn1 < tn0));
-      bool first1 = 2 * __popcll(pref1) > __popcll(both);
-      uint32_t nearc = first1 ? nd.c1 : nd.c0;
-      uint32_t farc = first1 ? nd.c0 : nd.c1;
-      W.stack[sp] = farc;
-      sp++;
-      next = nearc;
-    } else if (in0) {
-      next = nd.c0;
-    } else if (in1) {
-      next = nd.c1;
-    }
-    if (next == RT_NODE_EMPTY) {
-      if (sp == 0) break;
-      sp--;
-      next = W.stack[sp];
-    }
-    node = __builtin_amdgcn_readfirstlane(next);
   }
   return best;
 }
@@ -506,70 +522,79 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   };
 
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
-    for (uint32_t s = 0; s < sc.n_triangles; s++) test_tri(s, alive);
+    for (uint32_t s = 0; s < sc.n_slots; s++)
+      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, alive);
     return S;
   }
 
   const BoxRay br = box_ray(o, d);
   const float tl = t_limit_slack(tmax);
-  uint32_t sp = 0;
-  uint32_t node = 0;
+  const uint32_t lane_id = threadIdx.x & 63u;
   W.s_passes++;
-  for (;;) {
-    const RtNode nd = uload(&sc.nodes[node]);
-    float tn0, tn1;
-    bool live = alive && !S.occluded;
-    if (!__ballot(live)) break;
-    W.s_nodes++;
-    bool h0 = live && (nd.c0 != RT_NODE_EMPTY) && box_hit(nd.lo0, nd.hi0, br, tl, tn0);
-    bool h1 = live && (nd.c1 != RT_NODE_EMPTY) && box_hit(nd.lo1, nd.hi1, br, tl, tn1);
-    if (RT_DOUBLE & 4) {
-      BoxRay br2 = br;
-      RT_OPAQUE(br2.inv.x);
-      float a0, a1;
-      bool g0 = box_hit(nd.lo0, nd.hi0, br2, tl, a0), g1 = box_hit(nd.lo1, nd.hi1, br2, tl, a1);
-      h0 = h0 && (g0 || a0 == a0 || true);
-      h1 = h1 && (g1 || a1 == a1 || true);
-      if (g0 != g1 && a0 + a1 == 123.456f) h0 = !h0;
-    }
-    unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
-    uint32_t next = RT_NODE_EMPTY;
-    bool in0 = false, in1 = false;
-    if (b0) {
-      if (nd.n0) {
-        W.s_tris += nd.n0;
-        for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, h0);
-      } else {
-        in0 = true;
+  const unsigned long long grp = __ballot(alive);
+  {
+    uint32_t stk = 0;
+    uint32_t sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+      const unsigned long long live = grp & ~__ballot(S.occluded);
+      if (!live) break;
+      const RtNode nd = uload(&sc.nodes[node]);
+      W.s_nodes++;
+      float tn0, tn1;
+      bool h0, h1;
+      box_pair(nd, br, tl, h0, h1, tn0, tn1);
+      if (RT_DOUBLE & 4) {
+        BoxRay br2 = br;
+        RT_OPAQUE(br2.inv.x);
+        float a0, a1;
+        bool g0, g1;
+        box_pair(nd, br2, tl, g0, g1, a0, a1);
+        if (g0 != g1 && a0 + a1 == 123.456f) h0 = !h0;
       }
-    }
-    if (b1) {
-      if (nd.n1) {
-        W.s_tris += nd.n1;
-        for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, h1);
-      } else {
-        in1 = true;
+      const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & live) : 0ull;
+      const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & live) : 0ull;
+      uint32_t next = RT_NODE_EMPTY;
+      bool in0 = false, in1 = false;
+      if (b0) {
+        if (nd.n0) {
+          W.s_tris += nd.n0;
+          const bool on = (b0 >> lane_id) & 1ull;
+          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, on);
+        } else {
+          in0 = true;
+        }
       }
+      if (b1) {
+        if (nd.n1) {
+          W.s_tris += nd.n1;
+          const bool on = (b1 >> lane_id) & 1ull;
+          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, on);
+        } else {
+          in1 = true;
+        }
+      }
+      if (in0 && in1) {
+        // any-hit: visit the child that is nearer for most lanes first -- an early occluder ends the
+        // traversal for the whole wavefront
+        const unsigned long long both = b0 & b1;
+        const unsigned long long pref1 = __ballot(tn1 < tn0) & both;
+        const bool first1 = 2 * __popcll(pref1) > __popcll(both);
+        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
+        sp++;
+        next = first1 ? nd.c1 : nd.c0;
+      } else if (in0) {
+        next = nd.c0;
+      } else if (in1) {
+        next = nd.c1;
+      }
+      if (next == RT_NODE_EMPTY) {
+        if (sp == 0) break;
+        sp--;
+        next = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
+      }
+      node = next;
     }
-    if (in0 && in1) {
-      // any-hit: visit the child that is nearer for most lanes first -- an early occluder ends the
-      // traversal for the whole wavefront
-      unsigned long long pref1 = __ballot(h0 && h1 && (tn1 < tn0));
-      bool first1 = 2 * __popcll(pref1) > __popcll(b0 & b1);
-      W.stack[sp] = first1 ? nd.c0 : nd.c1;
-      sp++;
-      next = first1 ? nd.c1 : nd.c0;
-    } else if (in0) {
-      next = nd.c0;
-    } else if (in1) {
-      next = nd.c1;
-    }
-    if (next == RT_NODE_EMPTY) {
-      if (sp == 0) break;
-      sp--;
-      next = W.stack[sp];
-    }
-    node = __builtin_amdgcn_readfirstlane(next);
   }
   return S;
 }
@@ -587,8 +612,8 @@ __device__ __forceinline__ Surf surface_of(const RtDevScene& sc, Hit h, V3 o, V3
     s.n = normalize(s.p - mk(sp.x, sp.y, sp.z));
     s.mat = sc.sphere_mat[h.id];
   } else {
-    // tri_shade is stored in canonical order for this lookup (see rt_api.cpp)
-    float4 sh = sc.tri_shade[sc.n_triangles + (uint32_t)(h.id - (int)sc.n_spheres)];
+    // tri_shade holds a canonical-order copy behind the leaf-order one for this lookup (rt_api.cpp)
+    float4 sh = sc.tri_shade[sc.n_slots + (uint32_t)(h.id - (int)sc.n_spheres)];
     s.n = mk(sh.x, sh.y, sh.z);
     s.mat = __float_as_uint(sh.w);
   }
@@ -612,8 +637,7 @@ struct Wave {
   unsigned long long cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes;
 };
 
-__device__ __forceinline__ void wave_init(Wave& w, uint32_t* lds_stack) {
-  w.ctx.stack = lds_stack + (threadIdx.x >> 6) * RT_STACK_DEPTH;
+__device__ __forceinline__ void wave_init(Wave& w) {
   w.ctx.n_nodes = w.ctx.n_tris = w.ctx.s_nodes = w.ctx.s_tris = w.ctx.s_passes = w.ctx.n_exact = w.ctx.s_exact = 0;
   w.cnt_kind[0] = w.cnt_kind[1] = w.cnt_kind[2] = 0;
   w.cnt_shadow = w.cnt_pass = w.cnt_lanes = 0;
@@ -901,10 +925,10 @@ __device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c
 // reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
-__device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack,
+__device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P,
                                              float4* lds_rgbh) {
   Wave wv;
-  wave_init(wv, lds_stack);
+  wave_init(wv);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
   const uint32_t n_samples = aa ? P.aa_rays : 1u;
   const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
@@ -1007,21 +1031,20 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
 // MI355X, config 3: 4 waves/SIMD (122 VGPRs, no spills) 67.4 ms, 5 -> 61, 6 -> 58.4, 8 -> 62: the
 // traversal is a chain of dependent uniform loads + votes, so more resident waves beat fewer spills.
 __global__ __launch_bounds__(256, 6) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
-  __shared__ uint32_t lds_stack[RT_WAVES_PER_BLOCK * RT_STACK_DEPTH];
   __shared__ float4 lds_rgbh[256];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    primary_body<true>(sc, P, lds_stack, lds_rgbh);
+    primary_body<true>(sc, P, lds_rgbh);
   else
-    primary_body<false>(sc, P, lds_stack, lds_rgbh);
+    primary_body<false>(sc, P, lds_rgbh);
 }
 
 // ------------------------------------------------------------------------------------------------
 // secondary kernel: one thread per queued ray (reflection / refraction child of any depth)
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
-__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, uint32_t* lds_stack) {
+__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P) {
   Wave wv;
-  wave_init(wv, lds_stack);
+  wave_init(wv);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool have = i < P.q_in_count;
   RayIn r;
@@ -1052,11 +1075,10 @@ __device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDev
 }
 
 __global__ __launch_bounds__(256, 6) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
-  __shared__ uint32_t lds_stack[RT_WAVES_PER_BLOCK * RT_STACK_DEPTH];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    secondary_body<true>(sc, P, lds_stack);
+    secondary_body<true>(sc, P);
   else
-    secondary_body<false>(sc, P, lds_stack);
+    secondary_body<false>(sc, P);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -254,6 +254,7 @@ typedef struct rt_bvh_info {
   uint32_t max_leaf_size;
   uint64_t bytes_nodes;
   uint64_t bytes_triangles;
+  uint32_t n_references; /* triangle references in the leaves (>= n_triangles: split clipping) */
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
 
