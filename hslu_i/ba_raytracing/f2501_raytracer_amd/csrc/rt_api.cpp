@@ -75,6 +75,8 @@ struct rt_scene {
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host;
+  float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
+  float cloud_ball_f[3] = {0.f, 0.f, 0.f};
 };
 
 extern "C" {
@@ -296,9 +298,32 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     if (s->cloud_host.size() != n || memcmp(s->cloud_host.data(), p->cloud_sets, n * 4) != 0) {
       if ((rc = s->cloud.ensure(n * 4)) != RT_OK) return rc;
       s->cloud_host.assign(p->cloud_sets, p->cloud_sets + n);
+      s->cloud_ball[3] = -1.f;  // recompute the bounding ball
       HIP_TRY(hipMemcpyAsync(s->cloud.p, s->cloud_host.data(), n * 4, hipMemcpyHostToDevice, stream));
     }
     P->cloud_sets = (const float*)s->cloud.p;
+    // bounding ball of the offsets cs * (fw, fh, fd) over all sets (cached with the table)
+    if (s->cloud_ball[3] < 0.f || s->cloud_ball_f[0] != p->fw || s->cloud_ball_f[1] != p->fh || s->cloud_ball_f[2] != p->fd) {
+      s->cloud_ball_f[0] = p->fw, s->cloud_ball_f[1] = p->fh, s->cloud_ball_f[2] = p->fd;
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      const float f[3] = {p->fw, p->fh, p->fd};
+      for (size_t i = 0; i < n; i++) {
+        float v = s->cloud_host[i] * f[i % 3];
+        lo[i % 3] = std::fmin(lo[i % 3], v);
+        hi[i % 3] = std::fmax(hi[i % 3], v);
+      }
+      float r2 = 0.f;
+      for (int a = 0; a < 3; a++) {
+        s->cloud_ball[a] = 0.5f * (lo[a] + hi[a]);
+        float h = 0.5f * (hi[a] - lo[a]);
+        r2 += h * h;
+      }
+      s->cloud_ball[3] = std::sqrt(r2) * 1.001f + 1e-6f;
+    }
+    memcpy(P->cloud_centre, s->cloud_ball, 12);
+    P->cloud_delta = s->cloud_ball[3];
+    P->cand_cap = 64;
+    if (const char* e = getenv("RT_CAND_MAX")) P->cand_cap = (uint32_t)atoi(e) > 64u ? 64u : (uint32_t)atoi(e);  // experiments
   }
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;

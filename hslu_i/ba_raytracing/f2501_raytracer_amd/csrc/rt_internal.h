@@ -72,6 +72,11 @@ struct RtDevParams {
   const float* aa_offsets;   // device, [aa_rays][2]
   uint32_t light_mult, cloud_seed, n_cloud_sets;
   const float* cloud_sets;   // device, [n_sets][light_mult][3]
+  // bounding ball of all cloud offsets (scene units): offset of its centre from the light position and
+  // its radius (computed on the host over every set; 0 = unknown -> no candidate sharing)
+  float cloud_centre[3];
+  float cloud_delta;
+  uint32_t cand_cap;  // give up candidate sharing for a (wavefront, light) above this many slots (<= 64)
   uint32_t max_depth_reflection, max_depth_refraction;
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tile_size, n_ranks, rank;

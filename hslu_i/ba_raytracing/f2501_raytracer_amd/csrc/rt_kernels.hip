@@ -462,11 +462,110 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
 
 // ------------------------------------------------------------------------------------------------
 // shadow / transmittance ray: every hit <= tmax counts (raytracer.rs:24-106); a lane stops as soon
-// as it is completely occluded (its result is discarded by the caller, :800-802)
+// as it is completely occluded (its result is discarded by the caller, :800-802).
+//
+// Triangles are found in one of three ways:
+//   * RT_TRAVERSAL_LINEAR: the literal scan;
+//   * a BVH walk for this ray (light_mult == 1, or candidate overflow);
+//   * soft shadows (light_mult = N > 1): the N rays of one hit point towards the N jittered positions
+//     of one light differ by < cloud_delta everywhere along their length, so the BVH is walked ONCE
+//     per (wavefront, light) with the segment hit point -> cloud centre against boxes inflated by
+//     that delta (collect_light_candidates), and each of the N samples only tests the collected
+//     triangle slots.  The candidate set is a superset of what each sample's own walk would reach,
+//     every test is still the literal one, so results are unchanged; N-fold fewer node visits.
 // ------------------------------------------------------------------------------------------------
+#define RT_MAX_CANDIDATES 64u  /* one VGPR's worth of lanes */
+#define RT_CAND_OVERFLOW 0xFFFFFFFFu
+
+struct CandList {
+  uint32_t reg;    // lane i of this VGPR = i-th candidate triangle slot (wave-level list)
+  uint32_t count;  // uniform; RT_CAND_OVERFLOW = not usable, walk the BVH per sample instead
+};
+
+template <bool CULL>
+__device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
+                                                              float delta, uint32_t cand_cap) {
+  CandList L;
+  L.reg = 0;
+  L.count = 0;
+  const uint32_t lane_id = threadIdx.x & 63u;
+  // parametric segment x(s) = p + s*(c - p), s in [0, 1]
+  V3 dseg = c - p;
+  float len = fmaxf(mag(dseg), 1e-20f);
+  V3 inv = mk(clampf(__builtin_amdgcn_rcpf(dseg.x), -1e30f, 1e30f), clampf(__builtin_amdgcn_rcpf(dseg.y), -1e30f, 1e30f),
+              clampf(__builtin_amdgcn_rcpf(dseg.z), -1e30f, 1e30f));
+  V3 noi = mk(-(p.x * inv.x), -(p.y * inv.y), -(p.z * inv.z));
+  V3 dl = mk(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));  // box inflation in s units
+  float send = 1.0f + (delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f;     // past the cloud centre
+  float sbeg = -((delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f);
+  auto box = [&](const float* lo, const float* hi, float& smin) {
+    float tx1 = __builtin_fmaf(lo[0], inv.x, noi.x), tx2 = __builtin_fmaf(hi[0], inv.x, noi.x);
+    float ty1 = __builtin_fmaf(lo[1], inv.y, noi.y), ty2 = __builtin_fmaf(hi[1], inv.y, noi.y);
+    float tz1 = __builtin_fmaf(lo[2], inv.z, noi.z), tz2 = __builtin_fmaf(hi[2], inv.z, noi.z);
+    smin = fmaxf(fmaxf(fminf(tx1, tx2) - dl.x, fminf(ty1, ty2) - dl.y), fminf(tz1, tz2) - dl.z);
+    float smax = fminf(fminf(fmaxf(tx1, tx2) + dl.x, fmaxf(ty1, ty2) + dl.y), fmaxf(tz1, tz2) + dl.z);
+    float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
+    return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
+  };
+  const unsigned long long grp = __ballot(alive);
+  if (!grp) return L;
+  uint32_t stk = 0, sp = 0, node = 0;
+  for (;;) {
+    const RtNode nd = uload(&sc.nodes[node]);
+    W.s_nodes++;
+    float tn0, tn1;
+    bool h0 = box(nd.lo0, nd.hi0, tn0);
+    bool h1 = box(nd.lo1, nd.hi1, tn1);
+    const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & grp) : 0ull;
+    const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & grp) : 0ull;
+    // near-first order so that early occluders are tested first by every sample
+    const unsigned long long both = b0 & b1;
+    const bool first1 = both && (2 * __popcll(__ballot(tn1 < tn0) & both) > __popcll(both));
+    uint32_t next = RT_NODE_EMPTY;
+    bool in0 = false, in1 = false;
+    // leaves are appended in visiting order (nearer child first)
+    for (int pass = 0; pass < 2; pass++) {
+      const bool second = (pass == 1) != first1;  // which child this pass handles
+      const unsigned long long b = second ? b1 : b0;
+      const uint32_t cc = second ? nd.c1 : nd.c0, nn = second ? nd.n1 : nd.n0;
+      if (!b) continue;
+      if (nn) {
+        if (L.count + nn > cand_cap) {
+          L.count = RT_CAND_OVERFLOW;
+          return L;
+        }
+        for (uint32_t k = 0; k < nn; k++) {
+          L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
+          L.count++;
+        }
+      } else if (second) {
+        in1 = true;
+      } else {
+        in0 = true;
+      }
+    }
+    if (in0 && in1) {
+      stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
+      sp++;
+      next = first1 ? nd.c1 : nd.c0;
+    } else if (in0) {
+      next = nd.c0;
+    } else if (in1) {
+      next = nd.c1;
+    }
+    if (next == RT_NODE_EMPTY) {
+      if (sp == 0) break;
+      sp--;
+      next = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
+    }
+    node = next;
+  }
+  return L;
+}
+
 template <bool CULL>
 __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
-                                             bool alive, V3 o, V3 d_raw, float tmax) {
+                                             bool alive, V3 o, V3 d_raw, float tmax, const CandList& cand) {
   Shadow S;
   S.occluded = false;
   S.opacity = 1.0f;
@@ -526,12 +625,23 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, alive);
     return S;
   }
+  W.s_passes++;
+  const unsigned long long grp = __ballot(alive);
+
+  if (cand.count != RT_CAND_OVERFLOW) {
+    // soft shadows: test the triangle slots collected once for this (wavefront, light)
+    W.s_tris += cand.count;
+    for (uint32_t c = 0; c < cand.count; c++) {
+      if (!(grp & ~__ballot(S.occluded))) break;
+      uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)cand.reg, (int)c);
+      test_tri(slot, alive);
+    }
+    return S;
+  }
 
   const BoxRay br = box_ray(o, d);
   const float tl = t_limit_slack(tmax);
   const uint32_t lane_id = threadIdx.x & 63u;
-  W.s_passes++;
-  const unsigned long long grp = __ballot(alive);
   {
     uint32_t stk = 0;
     uint32_t sp = 0;
@@ -763,6 +873,13 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       cs = P.cloud_sets + (size_t)set * N * 3u;
       lI = (1.0f / (float)N) * L0.w;
     }
+    CandList cand;
+    cand.reg = 0;
+    cand.count = RT_CAND_OVERFLOW;
+    if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
+      V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
+      cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.cand_cap);
+    }
     for (uint32_t j = 0; j < N; j++) {
       V3 lp = mk(L0.x, L0.y, L0.z);
       if (N > 1 && hit) {
@@ -786,7 +903,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
       }
       wv.cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
-      Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax);
+      Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax, cand);
       bool reach = hit && !S.occluded;
       if (!__ballot(reach)) continue;
       // PointLight::calculate_contribution_at, light.rs:261-299
