@@ -507,6 +507,41 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
+  // Beam-level barycentric rejection.  Every sample ray j of this lane is (o_j, D_j) = (p + do, dseg + dd)
+  // with |do| <= eps_o, |dd| <= delta (un-normalised direction; u and v do not depend on its length).
+  // The literal numerators are linear in (o, D):
+  //   u_j * det_j = (c2 x D_j).(v1 - o_j) = (c2 x dseg).b + (c2 x dd).b - (c2 x D_j).do,   b = v1 - p
+  //   det_j = D_j.X = dseg.X + dd.X
+  // so with E2 = |e2|_1, B = |b|_1 + eps_o, Lp = len + delta:
+  //   |u_j det_j - (c2 x dseg).b| <= E2 * (delta*B + Lp*eps_o),   |det_j - dseg.X| <= delta*|X|_1
+  // A triangle is dropped for the whole beam when, with these slacks plus the rounding margin of the
+  // per-sample test (2e-6 * Lp * B * E), u < 0, v < 0 or u + v >= 1 holds for EVERY sample and the sign
+  // of det cannot change inside the beam.  Otherwise it stays a candidate (the per-sample test decides).
+  const float eps_o = delta;  // delta already contains 2*eps_distance; used as a (generous) bound on |do| too
+  const float lenp = len + delta;
+  auto beam_rejects = [&](uint32_t slot) -> bool {
+    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
+    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
+    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+    V3 c1 = mk(-q0.w, -q1.x, -q1.y), c2 = mk(-q1.z, -q1.w, -q2.x), x = mk(q2.y, q2.z, q2.w);
+    V3 b = mk(q0.x, q0.y, q0.z) - p;
+    V3 y = mk((c2.y * dseg.z) + (-c2.z * dseg.y), (c2.z * dseg.x) + (-c2.x * dseg.z), (c2.x * dseg.y) + (-c2.y * dseg.x));
+    V3 z = mk((dseg.y * c1.z) + (-dseg.z * c1.y), (dseg.z * c1.x) + (-dseg.x * c1.z), (dseg.x * c1.y) + (-dseg.y * c1.x));
+    float det = dot(dseg, x);
+    float E1 = fabsf(c1.x) + fabsf(c1.y) + fabsf(c1.z), E2 = fabsf(c2.x) + fabsf(c2.y) + fabsf(c2.z);
+    float X1 = fabsf(x.x) + fabsf(x.y) + fabsf(x.z);
+    float B = fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + eps_o;
+    float geo = __builtin_fmaf(delta, B, lenp * eps_o) + 2e-6f * lenp * B;  // per unit edge length
+    float ad = fabsf(det);
+    float dslack = __builtin_fmaf(delta, X1, 2e-6f * lenp * X1);
+    bool sign_known = ad > dslack * 1.001f;
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    float ybs = __uint_as_float(__float_as_uint(dot(y, b)) ^ sgn);
+    float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
+    float su = E2 * geo, sv = E1 * geo;
+    bool rej = (ybs + su < 0.0f) | (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
+    return sign_known & rej;
+  };
   const unsigned long long grp = __ballot(alive);
   if (!grp) return L;
   uint32_t stk = 0, sp = 0, node = 0;
@@ -534,7 +569,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
           L.count = RT_CAND_OVERFLOW;
           return L;
         }
+        const bool in_leaf = (b >> lane_id) & 1ull;
         for (uint32_t k = 0; k < nn; k++) {
+          if (!__ballot(in_leaf && !beam_rejects(cc + k))) continue;  // no sample of any lane can hit it
           L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
           L.count++;
         }
