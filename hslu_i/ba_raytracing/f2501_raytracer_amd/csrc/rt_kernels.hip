@@ -478,8 +478,9 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
 #define RT_CAND_OVERFLOW 0xFFFFFFFFu
 
 struct CandList {
-  uint32_t reg;    // lane i of this VGPR = i-th candidate triangle slot (wave-level list)
-  uint32_t count;  // uniform; RT_CAND_OVERFLOW = not usable, walk the BVH per sample instead
+  uint32_t reg;     // lane i of this VGPR = i-th candidate triangle slot (wave-level list)
+  uint32_t count;   // uniform; RT_CAND_OVERFLOW = not usable, walk the BVH per sample instead
+  uint32_t spheres; // uniform bit mask: sphere i (< 32) may be touched by some sample ray of some lane
 };
 
 template <bool CULL>
@@ -488,6 +489,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   CandList L;
   L.reg = 0;
   L.count = 0;
+  L.spheres = 0xFFFFFFFFu;
   const uint32_t lane_id = threadIdx.x & 63u;
   // parametric segment x(s) = p + s*(c - p), s in [0, 1]
   V3 dseg = c - p;
@@ -544,6 +546,23 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   };
   const unsigned long long grp = __ballot(alive);
   if (!grp) return L;
+  // spheres: every point of every sample ray lies within delta of the centre segment, so a sphere
+  // whose centre is farther than r + delta from that segment cannot be touched by any of them
+  {
+    uint32_t mask = 0;
+    const float inv_len2 = __builtin_amdgcn_rcpf(fmaxf(dot(dseg, dseg), 1e-30f));
+    const uint32_t ns = sc.n_spheres < 32u ? sc.n_spheres : 32u;
+    for (uint32_t i = 0; i < ns; i++) {
+      float4 sp4 = uload(&sc.spheres[i]);
+      V3 w = mk(sp4.x, sp4.y, sp4.z) - p;
+      float sp = clampf(dot(w, dseg) * inv_len2, 0.0f, 1.0f);
+      V3 q = w - dseg * sp;
+      float reach = __builtin_sqrtf(sp4.w) + delta;
+      bool near = dot(q, q) <= reach * reach * 1.0002f + 1e-12f;
+      if (__ballot(alive && near)) mask |= 1u << i;
+    }
+    L.spheres = mask | (sc.n_spheres > 32u ? 0xFFFFFFFFu : 0u);
+  }
   uint32_t stk = 0, sp = 0, node = 0;
   for (;;) {
     const RtNode nd = uload(&sc.nodes[node]);
@@ -609,6 +628,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   S.filter = mk(1.0f, 1.0f, 1.0f);
   V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
+    if (i < 32u && !((cand.spheres >> i) & 1u)) continue;  // culled for this (wavefront, light)
     float4 s = uload(&sc.spheres[i]);
     float t;
     bool h = alive && !S.occluded && sphere_hit(s, o, d, t);
@@ -913,6 +933,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     CandList cand;
     cand.reg = 0;
     cand.count = RT_CAND_OVERFLOW;
+    cand.spheres = 0xFFFFFFFFu;
     if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
       cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.cand_cap);
