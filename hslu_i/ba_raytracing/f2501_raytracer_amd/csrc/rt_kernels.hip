@@ -875,8 +875,9 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
+#define RT_STASH_FIELDS 13u
 __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
-                                              const RayIn& r) {
+                                              const RayIn& r, float* stash /* LDS: [RT_STASH_FIELDS][256] */) {
   RayOut out;
   out.hit = false;
   out.t = 0.0f;
@@ -911,14 +912,36 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   sf.mat = 0;
   if (hit) sf = surface_of(sc, h, r.o, d);
   Mat m = load_mat(sc, sf.mat);
-  // a reflection child's weight carries atten(child.t), known only now (:722-726)
-  float a = atten(h.t);
-  V3 Wt = r.Wt;
-  if (r.kind == KIND_REFL) Wt = Wt * a;
+  {
+    // Park what the light loop does not need in LDS (SoA, one dword per lane per field: conflict
+    // free).  The loop below runs lights x N shadow traversals; these 13 values would otherwise sit
+    // in VGPRs (or worse, in scratch = HBM traffic) for all of them.
+    // a reflection child's weight carries atten(child.t), known only now (:722-726)
+    float a0 = atten(h.t);
+    V3 W0 = r.Wt;
+    if (r.kind == KIND_REFL) W0 = W0 * a0;
+    float* st = stash + threadIdx.x;
+    st[0 * 256] = W0.x;
+    st[1 * 256] = W0.y;
+    st[2 * 256] = W0.z;
+    st[3 * 256] = a0;
+    st[4 * 256] = r.n_start;
+    st[5 * 256] = __int_as_float((r.depth << 2) | r.kind);
+    st[6 * 256] = m.metallic;
+    st[7 * 256] = m.ior;
+    st[8 * 256] = m.opacity;
+    st[9 * 256] = m.boost;
+    st[10 * 256] = m.transmissive ? 1.0f : 0.0f;
+    st[11 * 256] = h.t;
+    st[12 * 256] = __int_as_float(out.id);
+  }
+  const V3 mcolor = m.color;
+  const float mshin = m.shininess;
+  const uint32_t pixel = r.pix;
 
   // ---- calculate_lighting, raytracer_renderer.rs:731-874 ----------------------------------------
   V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
-  const bool has_spec = m.shininess > 0.0f;
+  const bool has_spec = mshin > 0.0f;
   for (uint32_t l = 0; l < sc.n_lights; l++) {
     const float4 L0 = uload(&sc.lights[2 * l + 0]);
     const float4 L1 = uload(&sc.lights[2 * l + 1]);
@@ -926,7 +949,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     const float* cs = nullptr;
     float lI = L0.w;
     if (N > 1) {
-      uint32_t set = rt_cloud_hash(P.cloud_seed, r.pix, l) % P.n_cloud_sets;
+      uint32_t set = rt_cloud_hash(P.cloud_seed, pixel, l) % P.n_cloud_sets;
       cs = P.cloud_sets + (size_t)set * N * 3u;
       lI = (1.0f / (float)N) * L0.w;
     }
@@ -971,7 +994,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       float att = 0.95f * (RT_EPS + dist + dist * dist);
       float sig = (tanhf(att) + 1.0f) / 2.0f;
       float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
-      V3 ccol = pos ? (m.color * lc) : mk(0, 0, 0);
+      V3 ccol = pos ? (mcolor * lc) : mk(0, 0, 0);
       float cint = pos ? lf : 0.0f;
       V3 Lc = mk(fast_div(ccol.x, S.filter.x), fast_div(ccol.y, S.filter.y), fast_div(ccol.z, S.filter.z));
       float diff = fmaxf(dot(sf.n, ld), 0.0f);
@@ -979,7 +1002,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       if (has_spec) {
         V3 rr = fast_normalize(reflected(ld, sf.n));
         float base = fmaxf(dot(rr, d), 0.0f);
-        specf = powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
+        specf = powf(base, fmaxf(mshin * 512.0f, 1.0f));
       }
       float light_factor = diff * cint * S.opacity;
       float spec_factor = cint * S.opacity * specf;
@@ -991,18 +1014,41 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         float att2 = 0.95f * (RT_EPS + dist2 + dist2 * dist2);
         float sig2 = (tanhf(att2) + 1.0f) / 2.0f;
         float lf2 = cosi2 * lI * clampf(sig2, 0.0f, 1.0f);
-        V3 Lc2 = (m.color * lc) / (S.filter + mk(dist2, dist2, dist2) * 0.0f);
+        V3 Lc2 = (mcolor * lc) / (S.filter + mk(dist2, dist2, dist2) * 0.0f);
         V3 ld3 = normalize(ltq);
         V3 rr2 = normalize(reflected(ld3, sf.n));
-        float sp2 = has_spec ? powf(fmaxf(dot(rr2, d), 0.0f), fmaxf(m.shininess * 512.0f, 1.0f)) : 0.0f;
+        float sp2 = has_spec ? powf(fmaxf(dot(rr2, d), 0.0f), fmaxf(mshin * 512.0f, 1.0f)) : 0.0f;
         if (lf2 + Lc2.x + Lc2.y + Lc2.z + sp2 == 123.456f) light_factor += 1.0f;
       }
       if (reach && diff > 0.0f) {
-        light_color = light_color + (m.color * Lc) * light_factor;
+        light_color = light_color + (mcolor * Lc) * light_factor;
         if (has_spec) spec_color = spec_color + lc * spec_factor;
       }
     }
   }
+  // ---- back from LDS -------------------------------------------------------------------------------
+  V3 Wt;
+  float a, n_start;
+  int depth, kind;
+  {
+    const float* st = stash + threadIdx.x;
+    Wt = mk(st[0 * 256], st[1 * 256], st[2 * 256]);
+    a = st[3 * 256];
+    n_start = st[4 * 256];
+    int dk = __float_as_int(st[5 * 256]);
+    depth = dk >> 2;
+    kind = dk & 3;
+    m.color = mcolor;
+    m.shininess = mshin;
+    m.metallic = st[6 * 256];
+    m.ior = st[7 * 256];
+    m.opacity = st[8 * 256];
+    m.boost = st[9 * 256];
+    m.transmissive = st[10 * 256] != 0.0f;
+    out.t = st[11 * 256];
+    out.id = __float_as_int(st[12 * 256]);
+  }
+  (void)kind;
   V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
   V3 direct = (ambient + light_color) * a;  // :206-209
   V3 spec = spec_color * a;
@@ -1026,22 +1072,22 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       bool inside = cos_theta < 0.0f;
       V3 inormal = inside ? -sf.n : sf.n;
       float n2 = inside ? m.ior : P.air_ior;
-      float eta = inside ? (n2 / r.n_start) : (r.n_start / n2);
+      float eta = inside ? (n2 / n_start) : (n_start / n2);
       float cos_i = fabsf(cos_theta);
       float sin2 = eta * eta * (1.0f - cos_i * cos_i);
       bool tir = sin2 >= 1.0f;
       bool reflective = (m.metallic > 0.0f) || (T && tir);
-      cdepth = r.depth < 0 ? (int)P.max_depth_reflection : (r.depth > 0 ? r.depth - 1 : 0);
+      cdepth = depth < 0 ? (int)P.max_depth_reflection : (depth > 0 ? depth - 1 : 0);
       if (reflective && cdepth > 0) {
         V3 rr = normalize(reflected(d, sf.n));
-        V3 Rf = fresnel_reflectance(m, inormal, -d, r.n_start);
+        V3 Rf = fresnel_reflectance(m, inormal, -d, n_start);
         spawn = true;
         co = sf.p + rr * epsv;
         cd = rr;
         cW = Wt * Rf;
       }
     }
-    queue_push(P, spawn, co, cd, r.n_start, cW, cdepth, KIND_REFL, r.pix);
+    queue_push(P, spawn, co, cd, n_start, cW, cdepth, KIND_REFL, pixel);
   }
   // ---- calculate_refractions, :279-524 --------------------------------------------------------------
   {
@@ -1054,7 +1100,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       bool inside = cos_theta <= 0.0f;
       V3 inormal = inside ? -sf.n : sf.n;
       float n2 = inside ? m.ior : P.air_ior;
-      float eta = inside ? (n2 / r.n_start) : (r.n_start / n2);
+      float eta = inside ? (n2 / n_start) : (n_start / n2);
       float inv_eta = 1.0f / eta;
       V3 Rf = fresnel_reflectance(m, inormal, d, inv_eta);
       V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
@@ -1065,7 +1111,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       float op = m.opacity;
       int step = (op < 0.5f) ? 2 : 1;
       int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
-      cdepth = r.depth < 0 ? (int)P.max_depth_refraction / fac : (r.depth > step ? r.depth - step : 0);
+      cdepth = depth < 0 ? (int)P.max_depth_refraction / fac : (depth > step ? depth - step : 0);
       if (!(kk < 0.0f) && cdepth > 0) {  // kk < 0: zero vector -> NaN direction -> miss (deviation D2)
         float s = inv_eta * ndi + __builtin_sqrtf(kk);
         V3 q = normalize(d * inv_eta - nn * s);
@@ -1076,7 +1122,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         cior = n2;
       }
     }
-    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, r.pix);
+    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, pixel);
   }
   return out;
 }
@@ -1100,8 +1146,8 @@ __device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c
 // reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
-__device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P,
-                                             float4* lds_rgbh) {
+__device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
+                                             float* lds_stash) {
   Wave wv;
   wave_init(wv);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
@@ -1139,7 +1185,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   r.kind = KIND_PRIMARY;
   r.pix = pix;
 
-  RayOut out = process_ray<CULL>(sc, P, wv, pix_on, r);
+  RayOut out = process_ray<CULL>(sc, P, wv, pix_on, r, lds_stash);
 
   // ---- per-pixel accumulation of the samples ----------------------------------------------------------
   V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
@@ -1202,22 +1248,25 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   wave_flush(wv, P, (unsigned long long)__popcll(__ballot(wrote)));
 }
 
-// __launch_bounds__(256, 6): 6 waves/SIMD (<= 80 VGPRs, ~170 B/lane of scratch spills).  Measured on
-// MI355X, config 3: 4 waves/SIMD (122 VGPRs, no spills) 67.4 ms, 5 -> 61, 6 -> 58.4, 8 -> 62: the
-// traversal is a chain of dependent uniform loads + votes, so more resident waves beat fewer spills.
-__global__ __launch_bounds__(256, 6) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
+// __launch_bounds__(256, 4): 127 VGPRs, NO scratch.  Measured on MI355X, config 3 (this kernel):
+// 4 waves/SIMD, no spills 37.7 ms | 5 waves, 144 B/lane scratch 35.3 ms | 6 waves, 220 B/lane 37.5 ms.
+// The 6 % of the 5-wave build is bought with ~40 GB of scratch traffic per frame through HBM
+// (rocprofv3 FETCH_SIZE/WRITE_SIZE: 1 TB/s, against 2.2 GB of algorithmic ray bytes); the spill-free
+// build keeps the kernel's HBM traffic at the framebuffer + scene level.
+__global__ __launch_bounds__(256, 4) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
+  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    primary_body<true>(sc, P, lds_rgbh);
+    primary_body<true>(sc, P, lds_rgbh, lds_stash);
   else
-    primary_body<false>(sc, P, lds_rgbh);
+    primary_body<false>(sc, P, lds_rgbh, lds_stash);
 }
 
 // ------------------------------------------------------------------------------------------------
 // secondary kernel: one thread per queued ray (reflection / refraction child of any depth)
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
-__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P) {
+__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, float* lds_stash) {
   Wave wv;
   wave_init(wv);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1244,16 +1293,17 @@ __device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDev
     r.Wt = mk(c.x, c.y, c.z);
     r.pix = __float_as_uint(c.w);
   }
-  RayOut out = process_ray<CULL>(sc, P, wv, have, r);
+  RayOut out = process_ray<CULL>(sc, P, wv, have, r, lds_stash);
   if (out.hit) acc_add(P, r.pix, out.contrib);
   wave_flush(wv, P, 0ull);
 }
 
-__global__ __launch_bounds__(256, 6) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
+__global__ __launch_bounds__(256, 4) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    secondary_body<true>(sc, P);
+    secondary_body<true>(sc, P, lds_stash);
   else
-    secondary_body<false>(sc, P);
+    secondary_body<false>(sc, P, lds_stash);
 }
 
 // ------------------------------------------------------------------------------------------------

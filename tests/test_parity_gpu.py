@@ -221,3 +221,19 @@ def test_tiny_triangle_counts_single_leaf_bvh(n_tris):
                      full.tri_v1[keep], full.tri_e1[keep], full.tri_e2[keep], full.tri_normal[keep],
                      full.tri_material[keep], full.materials, full.lights)
     compare(cfg, flat, None)
+
+
+def test_candidate_overflow_falls_back_to_per_sample_walk(monkeypatch):
+    """Soft shadows share one BVH walk per (wavefront, light); when the candidate list overflows the
+    kernel must fall back to a walk per sample with identical results.  RT_CAND_MAX (experiment knob
+    of the library) forces the overflow."""
+    cfg = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.semesterbild(cfg, "text_lowres").flatten()
+    win = (420, 330, 64, 48)
+    a_ref, p_ref, s_ref = gpu_render(cfg, flat, win)
+    for cap in ("0", "3"):
+        monkeypatch.setenv("RT_CAND_MAX", cap)
+        a, p, s_ = gpu_render(cfg, flat, win)
+        assert np.array_equal(a, a_ref) and np.array_equal(p["rgb"], p_ref["rgb"])
+        assert s_["rays_shadow"] == s_ref["rays_shadow"]
+    monkeypatch.delenv("RT_CAND_MAX")
