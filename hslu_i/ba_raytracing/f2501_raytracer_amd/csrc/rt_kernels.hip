@@ -810,25 +810,27 @@ __device__ __forceinline__ void wave_init(Wave& w) {
   w.cnt_shadow = w.cnt_pass = w.cnt_lanes = 0;
 }
 
-__device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, unsigned long long written) {
-  if ((threadIdx.x & 63u) == 0 && P.counters) {
-    // RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
-    // critical path (hundreds of thousands of wavefronts retire per frame); the host sums them
-    unsigned long long* c = P.counters + (size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u;
-    if (w.cnt_kind[0]) atomicAdd(&c[0], w.cnt_kind[0]);
-    if (w.cnt_kind[1]) atomicAdd(&c[1], w.cnt_kind[1]);
-    if (w.cnt_kind[2]) atomicAdd(&c[2], w.cnt_kind[2]);
-    if (w.cnt_shadow) atomicAdd(&c[3], w.cnt_shadow);
-    if (written) atomicAdd(&c[4], written);
-    if (w.cnt_pass) atomicAdd(&c[5], w.cnt_pass);
-    if (w.cnt_lanes) atomicAdd(&c[6], w.cnt_lanes);
-    if (w.ctx.n_nodes) atomicAdd(&c[7], w.ctx.n_nodes);
-    if (w.ctx.n_tris) atomicAdd(&c[8], w.ctx.n_tris);
-    if (w.ctx.s_nodes) atomicAdd(&c[9], w.ctx.s_nodes);
-    if (w.ctx.s_tris) atomicAdd(&c[10], w.ctx.s_tris);
-    if (w.ctx.s_passes) atomicAdd(&c[11], w.ctx.s_passes);
-    if (w.ctx.n_exact) atomicAdd(&c[12], w.ctx.n_exact);
-    if (w.ctx.s_exact) atomicAdd(&c[13], w.ctx.s_exact);
+// Statistics: the wavefronts of a workgroup add their counters in LDS, then 14 threads issue one global
+// atomic each (RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
+// critical path; the host sums them).  Every thread of the workgroup must call this (two barriers).
+#define RT_N_COUNTERS 14u
+__device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, unsigned long long written,
+                                           unsigned long long* lds_cnt) {
+  if (!P.counters) return;  // wave-uniform (kernel argument)
+  if (threadIdx.x < RT_N_COUNTERS) lds_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) {
+    const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
+                                                 w.cnt_pass,    w.cnt_lanes,   w.ctx.n_nodes,  w.ctx.n_tris, w.ctx.s_nodes,
+                                                 w.ctx.s_tris,  w.ctx.s_passes, w.ctx.n_exact, w.ctx.s_exact};
+#pragma unroll
+    for (unsigned i = 0; i < RT_N_COUNTERS; i++)
+      if (v[i]) atomicAdd(&lds_cnt[i], v[i]);
+  }
+  __syncthreads();
+  if (threadIdx.x < RT_N_COUNTERS) {
+    unsigned long long v = lds_cnt[threadIdx.x];
+    if (v) atomicAdd(&P.counters[(size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u + threadIdx.x], v);
   }
 }
 
@@ -1147,7 +1149,7 @@ __device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
 __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
-                                             float* lds_stash) {
+                                             float* lds_stash, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
@@ -1245,7 +1247,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       }
     }
   }
-  wave_flush(wv, P, (unsigned long long)__popcll(__ballot(wrote)));
+  wave_flush(wv, P, (unsigned long long)__popcll(__ballot(wrote)), lds_cnt);
 }
 
 // __launch_bounds__(256, 4): 127 VGPRs, NO scratch.  Measured on MI355X, config 3 (this kernel):
@@ -1256,17 +1258,19 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
 __global__ __launch_bounds__(256, 4) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    primary_body<true>(sc, P, lds_rgbh, lds_stash);
+    primary_body<true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   else
-    primary_body<false>(sc, P, lds_rgbh, lds_stash);
+    primary_body<false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // secondary kernel: one thread per queued ray (reflection / refraction child of any depth)
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
-__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, float* lds_stash) {
+__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, float* lds_stash,
+                                               unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1295,15 +1299,16 @@ __device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDev
   }
   RayOut out = process_ray<CULL>(sc, P, wv, have, r, lds_stash);
   if (out.hit) acc_add(P, r.pix, out.contrib);
-  wave_flush(wv, P, 0ull);
+  wave_flush(wv, P, 0ull, lds_cnt);
 }
 
 __global__ __launch_bounds__(256, 4) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    secondary_body<true>(sc, P, lds_stash);
+    secondary_body<true>(sc, P, lds_stash, lds_cnt);
   else
-    secondary_body<false>(sc, P, lds_stash);
+    secondary_body<false>(sc, P, lds_stash, lds_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
