@@ -237,3 +237,28 @@ def test_candidate_overflow_falls_back_to_per_sample_walk(monkeypatch):
         assert np.array_equal(a, a_ref) and np.array_equal(p["rgb"], p_ref["rgb"])
         assert s_["rays_shadow"] == s_ref["rays_shadow"]
     monkeypatch.delenv("RT_CAND_MAX")
+
+
+def test_extreme_quality_24_samples_ragged_workgroups():
+    """24 rays/pixel (extreme_quality): a 256-thread workgroup holds 10 pixels (240 lanes), so pixel
+    groups straddle wavefronts and 4x4 tiles; N_cloud = 28."""
+    cfg = RenderConfig.from_features(["extreme_quality", "reflections", "refractions"], n_cloud_sets=16, depth_override=3)
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (401, 263, 37, 23))
+
+
+def test_config5_4k_aspect_window():
+    """BASELINE config 5 geometry: 3840x2160 changes the scene itself (16:9 constants, lib.rs:73-92)."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=3840,
+                                     height_override=2160, n_cloud_sets=32, depth_override=4)
+    flat = scenes.semesterbild(cfg, "text_lowres").flatten()
+    compare(cfg, flat, (1800, 900, 40, 24))
+    compare(cfg, flat, (2900, 1700, 24, 16))
+
+
+def test_window_smaller_than_a_tile_and_single_pixel():
+    cfg = RenderConfig.from_features(["anti_aliasing"])
+    flat = scenes.test_scene(cfg).flatten()
+    compare(cfg, flat, (123, 77, 1, 1))
+    compare(cfg, flat, (0, 0, 3, 2))
+    compare(cfg, flat, (cfg.width - 1, cfg.height - 1, 1, 1))
