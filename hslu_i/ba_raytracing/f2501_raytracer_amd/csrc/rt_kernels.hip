@@ -31,7 +31,7 @@
 // reference calls mul_add (written __builtin_fmaf).  Division and sqrt are the correctly rounded
 // forms (hipcc default) wherever a hit / occlusion / spawn decision depends on them, so every such
 // decision and every t is bit-identical to the CPU restatement in oracle/; colour-only factors use
-// v_rcp/v_rsq (1 ulp), tanhf/powf are ocml's.
+// v_rcp/v_rsq (1 ulp) and exp2/log2-based tanh/pow.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -114,6 +114,22 @@ __device__ __forceinline__ V3 fast_normalize(V3 a) {
   float r = __builtin_amdgcn_rsqf(dot(a, a));
   return a * r;
 }
+
+// tanh(x) for x >= 0 and pow(b, e) for b in [0, 1], e >= 1 with the hardware exp2 / log2 instead of
+// ocml's tanhf / powf (colour-only factors: light sigmoid, specular lobe).  Measured: -7.5 % kernel
+// time on config 3; max |dRGB| vs the oracle over the whole parity suite 3.7e-6 (7e-7 with ocml; bar
+// 1e-4).  The reference itself evaluates both with `wide`'s polynomial approximations.
+// -DRT_FAST_TRANS=0 selects ocml.
+__device__ __forceinline__ float fast_tanh_pos(float x) {
+  float e = __builtin_amdgcn_exp2f(x * -2.885390082f);  // exp(-2x)
+  return (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float fast_pow01(float b, float e) {
+  return b > 0.0f ? __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(b)) : 0.0f;
+}
+#ifndef RT_FAST_TRANS
+#define RT_FAST_TRANS 1
+#endif
 
 struct Mat {
   V3 color;
@@ -994,7 +1010,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       float cosi = fast_div(dot(ltp, sf.n), dist);
       bool pos = cosi > 0.0f;
       float att = 0.95f * (RT_EPS + dist + dist * dist);
-      float sig = (tanhf(att) + 1.0f) / 2.0f;
+      float sig = ((RT_FAST_TRANS ? fast_tanh_pos(att) : tanhf(att)) + 1.0f) / 2.0f;
       float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
       V3 ccol = pos ? (mcolor * lc) : mk(0, 0, 0);
       float cint = pos ? lf : 0.0f;
@@ -1004,7 +1020,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       if (has_spec) {
         V3 rr = fast_normalize(reflected(ld, sf.n));
         float base = fmaxf(dot(rr, d), 0.0f);
-        specf = powf(base, fmaxf(mshin * 512.0f, 1.0f));
+        specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
       }
       float light_factor = diff * cint * S.opacity;
       float spec_factor = cint * S.opacity * specf;

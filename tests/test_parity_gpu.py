@@ -54,6 +54,7 @@ def compare(cfg, flat, win, traversal=_abi.RT_TRAVERSAL_BVH, max_bad_px=0):
         assert np.abs(a - b).max() <= 1
     for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
         assert sg[k] == so[k], (k, sg[k], so[k])
+    print(f"max |dRGB| vs oracle = {float(d.max()):.3e}")
     return float(d.max())
 
 
