@@ -979,12 +979,17 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
       cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.cand_cap);
     }
+    // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
+    // the load latency hides under a whole shadow traversal
+    V3 cnext = mk(0, 0, 0);
+    if (N > 1 && hit) cnext = mk(cs[0], cs[1], cs[2]);
     for (uint32_t j = 0; j < N; j++) {
       V3 lp = mk(L0.x, L0.y, L0.z);
-      if (N > 1 && hit) {
-        lp.x = L0.x + cs[3 * j + 0] * P.fw;  // light.rs:218
-        lp.y = L0.y + cs[3 * j + 1] * P.fh;
-        lp.z = L0.z + cs[3 * j + 2] * P.fd;
+      if (N > 1) {
+        lp.x = L0.x + cnext.x * P.fw;  // light.rs:218
+        lp.y = L0.y + cnext.y * P.fh;
+        lp.z = L0.z + cnext.z * P.fd;
+        if (hit && j + 1 < N) cnext = mk(cs[3 * j + 3], cs[3 * j + 4], cs[3 * j + 5]);
       }
       V3 ltp = lp - sf.p;
       V3 ld = normalize(ltp);
