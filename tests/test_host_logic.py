@@ -215,3 +215,25 @@ def test_tiles_cover_every_pixel_exactly_once(n_ranks):
     assert own.shape == (29, 34)  # 34 x 29 tiles at 1620x1350
     if n_ranks > 1:  # neighbouring tiles never share a rank
         assert (own[:, 1:] != own[:, :-1]).all() and (own[1:, :] != own[:-1, :]).all()
+
+
+def test_output_encoder_matches_oracle_pack(oracle, tmp_path):
+    """WindowColorEncoder::to_output (window.rs:105-109) host mirror == the oracle's pack, and FileOutput
+    writes the buffer's RGB8 rows (file.rs:27-49)."""
+    import ctypes as C
+    from PIL import Image
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.output import FileOutput, WindowColorEncoder
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import ImageBuffer
+    rng = np.random.default_rng(5)
+    cases = [(1.0, 0.5, 0.0), (0.5 / 255, 1.5 / 255, 2.5 / 255), (2.0, -1.0, 1.0)] + [tuple(rng.uniform(-0.2, 1.2, 3)) for _ in range(200)]
+    for rgb in cases:
+        want = oracle.rt_oracle_pack(*[C.c_float(c) for c in rgb])
+        assert WindowColorEncoder.to_output(rgb) == want
+    assert WindowColorEncoder.to_output((1.0, 0.5, 0.0)) == 0xFFFF8000
+    assert WindowColorEncoder.from_output(0xFF336699) == pytest.approx((0.2, 0.4, 0.6))
+    buf = ImageBuffer.new(4, 2)
+    buf.buffer[:] = [0xFFFF0000, 0xFF00FF00, 0xFF0000FF, 0, 0xFF102030, 0xFFFFFFFF, 0, 0xFF808080]
+    path = str(tmp_path / "o.png")
+    FileOutput.new(path).render_buffer(buf)
+    img = np.asarray(Image.open(path))
+    assert img.shape == (2, 4, 3) and img[0, 0].tolist() == [255, 0, 0] and img[1, 0].tolist() == [0x10, 0x20, 0x30]

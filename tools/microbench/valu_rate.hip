@@ -6,7 +6,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP 64
 template <int MODE>
-__global__ void k(float* out, int iters) {
+__global__ void k(float* out, int iters, const float* __restrict__ uni) {
+  const float su0 = uni[0], su1 = uni[1];
+  unsigned long long acc = 0;
   float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
   const float m = 1.0000001f, c = 1e-7f;
@@ -42,6 +44,17 @@ __global__ void k(float* out, int iters) {
         b = __ballot(a6 > a7); a6 += (float)__popcll(b) * c; a7 *= m;
       } else if (MODE == 10) {  // 4 fast rcp (v_rcp_f32 only)
         a0 = __builtin_amdgcn_rcpf(a0) + m; a1 = __builtin_amdgcn_rcpf(a1) + m; a2 = __builtin_amdgcn_rcpf(a2) + m; a3 = __builtin_amdgcn_rcpf(a3) + m;
+      } else if (MODE == 11) {  // 8 fma with an SGPR operand (uniform value from a scalar load)
+        a0 = __builtin_fmaf(a0, su0, c); a1 = __builtin_fmaf(a1, su1, c); a2 = __builtin_fmaf(a2, su0, c); a3 = __builtin_fmaf(a3, su1, c);
+        a4 = __builtin_fmaf(a4, su0, c); a5 = __builtin_fmaf(a5, su1, c); a6 = __builtin_fmaf(a6, su0, c); a7 = __builtin_fmaf(a7, su1, c);
+      } else if (MODE == 12) {  // 8 mul+add pairs not contracted, SGPR operand
+        a0 = a0 * su0 + c; a1 = a1 * su1 + c; a2 = a2 * su0 + c; a3 = a3 * su1 + c;
+        a4 = a4 * su0 + c; a5 = a5 * su1 + c; a6 = a6 * su0 + c; a7 = a7 * su1 + c;
+      } else if (MODE == 13) {  // 8 compares into masks + ballots (v_cmp only)
+        unsigned long long m0 = __ballot(a0 > su0), m1 = __ballot(a1 > su1), m2 = __ballot(a2 < su0), m3 = __ballot(a3 < su1);
+        unsigned long long m4 = __ballot(a4 > su0), m5 = __ballot(a5 > su1), m6 = __ballot(a6 < su0), m7 = __ballot(a7 < su1);
+        acc += m0 ^ m1 ^ m2 ^ m3 ^ m4 ^ m5 ^ m6 ^ m7;
+        a0 += c;
       } else if (MODE == 4) {  // 8 scalar max
         a0 = fmaxf(a0, c); a1 = fmaxf(a1, m); a2 = fmaxf(a2, c); a3 = fmaxf(a3, m);
         a4 = fmaxf(a4, c); a5 = fmaxf(a5, m); a6 = fmaxf(a6, c); a7 = fmaxf(a7, m);
@@ -49,7 +62,7 @@ __global__ void k(float* out, int iters) {
       }
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(acc & 1);
 }
 
 template <int MODE>
@@ -61,9 +74,10 @@ void run(const char* name, int waves_per_simd, int n_instr_per_rep) {
   int iters = 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE><<<blocks, threads>>>(out, 10);
+  float* uni; hipMalloc(&uni, 64); float hu[2] = {1.0000001f, 0.9999999f}; hipMemcpy(uni, hu, 8, hipMemcpyHostToDevice);
+  k<MODE><<<blocks, threads>>>(out, 10, uni);
   hipEventRecord(e0);
-  k<MODE><<<blocks, threads>>>(out, iters);
+  k<MODE><<<blocks, threads>>>(out, iters, uni);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -87,6 +101,9 @@ int main() {
     run<8>("minmax3+add x8", w, 8);
     run<9>("ballot grp x4", w, 4);
     run<10>("rcp+add x4", w, 4);
+    run<11>("fma sgpr x8", w, 8);
+    run<12>("mul,add sgpr x16", w, 16);
+    run<13>("cmp->mask x8(+1)", w, 9);
   }
   return 0;
 }
