@@ -71,7 +71,9 @@ struct rt_scene {
   rt_bvh_info info{};
   DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes;
   // per-render workspaces
-  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t;
+  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist;
+  std::vector<uint32_t> sup_host;
+  uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host;
@@ -93,7 +95,7 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
-                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->fb, &s->aux_rgb,
+                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -260,6 +262,7 @@ static int validate_params(const rt_params* p) {
   if (p->light_mult > 1 && (!p->cloud_sets || p->n_cloud_sets == 0))
     return fail(RT_ERR_INVALID_ARG, "cloud_sets missing");
   if (p->n_ranks > 1 && p->rank >= p->n_ranks) return fail(RT_ERR_INVALID_ARG, "rank out of range");
+  if (p->n_ranks > 1 && p->tile_size != 0 && p->tile_size < 16) return fail(RT_ERR_UNSUPPORTED, "tile_size < 16");
   if (p->traversal > RT_TRAVERSAL_LINEAR) return fail(RT_ERR_INVALID_ARG, "unknown traversal mode");
   if (p->max_depth_reflection > 64 || p->max_depth_refraction > 64)
     return fail(RT_ERR_UNSUPPORTED, "recursion depth > 64");
@@ -349,6 +352,33 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
 
   const bool aa_on = P->aa_rays > 0;
   if (aa_on && P->aa_rays > 256) return fail(RT_ERR_UNSUPPORTED, "aa_rays > 256");
+  // multi-GPU: launch workgroups only for the super-tiles that hold pixels of this rank's tiles
+  P->sup_list = nullptr;
+  P->n_sup = 0;
+  if (P->n_ranks > 1) {
+    const uint32_t key[7] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->tile_size, P->n_ranks, P->rank};
+    if (memcmp(key, s->sup_key, sizeof(key)) != 0 || s->sup_host.empty()) {
+      s->sup_host.clear();
+      const uint32_t st_x = (P->win_w + 15u) / 16u, st_y = (P->win_h + 15u) / 16u;
+      for (uint32_t sy = 0; sy < st_y; sy++)
+        for (uint32_t sx = 0; sx < st_x; sx++) {
+          // a 16x16 super-tile spans at most 2 tiles per axis (tile_size >= 16): its corners decide
+          uint32_t x0 = P->win_x0 + sx * 16u, y0 = P->win_y0 + sy * 16u;
+          uint32_t x1 = x0 + 15u < P->win_x0 + P->win_w - 1u ? x0 + 15u : P->win_x0 + P->win_w - 1u;
+          uint32_t y1 = y0 + 15u < P->win_y0 + P->win_h - 1u ? y0 + 15u : P->win_y0 + P->win_h - 1u;
+          bool own = false;
+          for (uint32_t yy : {y0, y1})
+            for (uint32_t xx : {x0, x1})
+              own = own || rt_tile_owner(xx / P->tile_size, yy / P->tile_size, P->n_ranks) == P->rank;
+          if (own) s->sup_host.push_back(sy * st_x + sx);
+        }
+      memcpy(s->sup_key, key, sizeof(key));
+      if ((rc = s->suplist.ensure(s->sup_host.size() * 4 + 4)) != RT_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(s->suplist.p, s->sup_host.data(), s->sup_host.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    P->sup_list = (const uint32_t*)s->suplist.p;
+    P->n_sup = (uint32_t)s->sup_host.size();
+  }
   return RT_OK;
 }
 

@@ -98,6 +98,10 @@ struct RtDevParams {
   uint32_t q_in_first, q_in_count;
   long long* acc;         // [W*H][4] fixed-point RGB accumulator + primary-hit flag (nullptr: direct write)
   uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
+  // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;
+  // nullptr = all super-tiles of the window
+  const uint32_t* sup_list;
+  uint32_t n_sup;
 };
 
 #define RT_BLOCK_W 16u

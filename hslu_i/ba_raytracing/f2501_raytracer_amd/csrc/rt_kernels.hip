@@ -1178,12 +1178,15 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
   const uint32_t slot = threadIdx.x / n_samples;
   const uint32_t k = threadIdx.x - slot * n_samples;
-  const bool lane_used = slot < ppw;
-  // pixel index in tile order -> window coordinates
+  // workgroup -> 16x16 super-tile (through the list of super-tiles this rank owns, if any) -> pixel
   const uint32_t st_x = (P.win_w + 15u) / 16u;
-  const uint32_t lin = (P.batch_first_wg + blockIdx.x) * ppw + slot;
-  const uint32_t sup = lin >> 8, in_sup = lin & 255u;
-  const uint32_t t4 = in_sup >> 4, p4 = in_sup & 15u;
+  const uint32_t wgs_per_sup = (256u + ppw - 1u) / ppw;
+  const uint32_t wg = P.batch_first_wg + blockIdx.x;
+  const uint32_t sup_slot = wg / wgs_per_sup;
+  const uint32_t sup = P.sup_list ? uload(&P.sup_list[sup_slot]) : sup_slot;
+  const uint32_t in_sup = (wg - sup_slot * wgs_per_sup) * ppw + slot;
+  const bool lane_used = (slot < ppw) && (in_sup < 256u);
+  const uint32_t t4 = (in_sup >> 4) & 15u, p4 = in_sup & 15u;
   const uint32_t lx = (sup % st_x) * 16u + (t4 & 3u) * 4u + (p4 & 3u);
   const uint32_t ly = (sup / st_x) * 16u + (t4 >> 2) * 4u + (p4 >> 2);
   const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
@@ -1365,11 +1368,12 @@ uint32_t rt_primary_pixels_per_wg(const RtDevParams& p) {
   return 256u / (aa ? p.aa_rays : 1u);
 }
 
+// workgroups of the primary kernel: every (listed) 16x16 super-tile takes ceil(256 / ppw) of them
 uint32_t rt_primary_total_wgs(const RtDevParams& p) {
   uint32_t st_x = (p.win_w + 15u) / 16u, st_y = (p.win_h + 15u) / 16u;
-  uint64_t lin = (uint64_t)st_x * st_y * 256u;
+  uint32_t n_sup = p.sup_list ? p.n_sup : st_x * st_y;
   uint32_t ppw = rt_primary_pixels_per_wg(p);
-  return (uint32_t)((lin + ppw - 1) / ppw);
+  return n_sup * ((256u + ppw - 1u) / ppw);
 }
 
 // experiments only: RT_DEBUG_LDS_PAD=<bytes> adds unused dynamic LDS to throttle occupancy
@@ -1383,6 +1387,7 @@ static unsigned debug_lds_pad() {
 }
 
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) return 0;  // nothing owned inside the window
   hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), debug_lds_pad(), (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }

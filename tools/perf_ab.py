@@ -24,7 +24,9 @@ if "--reps" in args:
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 for spec in args or ["c3"]:
+    spec, _, rk = spec.partition("@")  # name[:window][@rank/n_ranks]
     name, _, win = spec.partition(":")
+    rank, n_ranks = (int(v) for v in rk.split("/")) if rk else (0, 1)
     window = tuple(int(v) for v in win.split(",")) if win else None
     if name.startswith("sem="):
         # sem=feat+feat[/depth][/model]  e.g. sem=high_resolution+realistic+high_quality/8/text
@@ -40,7 +42,7 @@ for spec in args or ["c3"]:
     else:
         cfg, flat, _ = bench.build_workload(name)
     ds = DeviceScene(flat, 0)
-    p, keep = _abi.make_params(cfg, window=window)
+    p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank)
     fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
     times = []
     for r in range(reps + 1):
