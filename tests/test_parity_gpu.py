@@ -263,3 +263,66 @@ def test_window_smaller_than_a_tile_and_single_pixel():
     compare(cfg, flat, (123, 77, 1, 1))
     compare(cfg, flat, (0, 0, 3, 2))
     compare(cfg, flat, (cfg.width - 1, cfg.height - 1, 1, 1))
+
+
+def random_scene(seed, n_spheres, n_tris, n_lights, cfg):
+    """Seeded random soup: spheres and triangles of mixed sizes (incl. slivers and near-degenerate ones),
+    diffuse / metallic / transmissive materials, lights inside the view volume."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import FlatScene
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    sh = float(cfg.scene_height)
+    sd = float(cfg.scene_depth)
+    mats = []
+    for _ in range(12):
+        kind = rng.integers(0, 4)
+        col = rng.uniform(0.05, 1.0, 3)
+        if kind == 0:    # diffuse
+            mats.append([*col, 0, rng.uniform(0, 0.6), 1, 0, 0, 0])
+        elif kind == 1:  # metallic
+            mats.append([*col, rng.uniform(0.1, 1.0), rng.uniform(0, 0.5), 0, 0, 0, 0])
+        elif kind == 2:  # transmissive
+            mats.append([*col, 0, rng.uniform(0, 0.5), rng.uniform(1.1, 1.9), rng.uniform(0.55, 1.0), rng.uniform(0, 0.3), 1])
+        else:            # transmissive + metallic
+            mats.append([*col, rng.uniform(0.05, 0.4), rng.uniform(0, 0.5), rng.uniform(1.1, 1.9), rng.uniform(0.55, 1.0), 0, 1])
+    mats = np.asarray(mats, f32)
+    box_lo, box_hi = np.array([0.05, 0.05, 0.1]), np.array([0.95, sh - 0.05, sd])
+    sc = rng.uniform(box_lo, box_hi, (n_spheres, 3)).astype(f32)
+    sr = rng.uniform(0.02, 0.12, n_spheres).astype(f32)
+    v1 = rng.uniform(box_lo, box_hi, (n_tris, 3)).astype(f32)
+    scale = np.where(rng.random(n_tris) < 0.2, 0.3, 0.05)[:, None]
+    e1 = (rng.normal(0, 1, (n_tris, 3)) * scale).astype(f32)
+    e2 = (rng.normal(0, 1, (n_tris, 3)) * scale).astype(f32)
+    sliver = rng.random(n_tris) < 0.25
+    e2[sliver] = (e1[sliver] * rng.uniform(0.3, 1.0, (sliver.sum(), 1)) + rng.normal(0, 2e-3, (sliver.sum(), 3))).astype(f32)
+    tiny = rng.random(n_tris) < 0.05
+    e1[tiny] *= f32(1e-3)
+    nrm = np.cross(e1, e2)
+    nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)).astype(f32)
+    odd = rng.random(n_tris) < 0.3  # non-unit stored normals, like the OBJ path
+    nrm[odd] *= rng.uniform(0.2, 1.0, (odd.sum(), 1)).astype(f32)
+    lights = np.zeros((n_lights, 7), f32)
+    lights[:, :3] = rng.uniform([0.1, 0.05, 0.0], [0.9, sh * 0.6, sd * 0.5], (n_lights, 3))
+    lights[:, 3:6] = rng.uniform(0.4, 1.0, (n_lights, 3))
+    lights[:, 6] = rng.uniform(0.2, 0.8, n_lights)
+    return FlatScene(sc, (sr * sr).astype(f32), (1 / sr).astype(f32), rng.integers(0, len(mats), n_spheres).astype(np.uint32),
+                     v1, e1, e2, nrm, rng.integers(0, len(mats), n_tris).astype(np.uint32), mats, lights)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_random_scenes_all_features(seed):
+    """Fuzz: every conservative shortcut of the kernel (padded BVH boxes, triangle pre-filter, shared
+    soft-shadow candidates with beam rejection, sphere culling, ray streaming) against the brute-force
+    oracle on random geometry with all features on."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160,
+                                     height_override=128, n_cloud_sets=16, depth_override=3, cloud_seed=seed)
+    flat = random_scene(seed, n_spheres=6 + seed, n_tris=300 + 100 * seed, n_lights=3, cfg=cfg)
+    compare(cfg, flat, (40 + 8 * seed, 30, 56, 40))
+
+
+def test_random_scene_shadows_only_dense():
+    """Same, many small triangles and big light clouds, no secondary rays (the headline kernel path)."""
+    cfg = RenderConfig.from_features(["anti_aliasing", "high_quality"], width_override=192, height_override=160,
+                                     n_cloud_sets=8, cloud_seed=7)
+    flat = random_scene(11, n_spheres=4, n_tris=2500, n_lights=4, cfg=cfg)
+    compare(cfg, flat, (60, 50, 48, 40))
