@@ -35,6 +35,9 @@ WORKLOADS = {
     # BASELINE.json configs[2]
     "c3": dict(features=["high_resolution", "anti_aliasing", "soft_shadows"], model="text", scene="semesterbild",
                name="semesterbild@high_resolution+anti_aliasing+soft_shadows (text.obj)"),
+    # configs[0]: the reference's own CPU-runnable case (here also on the GPU)
+    "c1": dict(features=[], model=None, scene="test_scene",
+               name="test_scene@768x640, no AA / reflections"),
     # configs[1]
     "c2": dict(features=["medium_resolution"], model=None, scene="test_scene_spheres",
                name="test_scene spheres-only@medium_resolution, no secondary rays"),
@@ -56,6 +59,8 @@ def build_workload(key):
                                      height_override=size[1])
     if w["scene"] == "semesterbild":
         flat = scenes.semesterbild(cfg, w["model"]).flatten()
+    elif w["scene"] == "test_scene":
+        flat = scenes.test_scene(cfg).flatten()
     else:
         flat = scenes.test_scene(cfg).flatten().without_triangles()
     return cfg, flat, w["name"]

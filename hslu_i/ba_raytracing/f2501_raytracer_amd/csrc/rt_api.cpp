@@ -71,7 +71,7 @@ struct rt_scene {
   rt_bvh_info info{};
   DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes;
   // per-render workspaces
-  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist;
+  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
@@ -95,7 +95,7 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
-                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->fb, &s->aux_rgb,
+                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -412,8 +412,18 @@ static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels,
       P.q_out = nullptr;  // rays of the last level have depth 1: no children possible
       P.q_out_count = nullptr;
     }
-    hipError_t e = (hipError_t)rt_launch_secondary(s->dev, P, stream);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "secondary launch failed: %s", hipGetErrorString(e));
+    // trace -> sort by hit point -> shade
+    hipError_t e = (hipError_t)rt_launch_trace(s->dev, P, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
+    {
+      uint32_t* w = (uint32_t*)s->trace_ws.p;
+      size_t tmp_bytes = s->sort_tmp.cap;
+      e = (hipError_t)rt_sort_pairs(w + 2 * (size_t)RT_CHUNK, w + 3 * (size_t)RT_CHUNK, w + 4 * (size_t)RT_CHUNK,
+                                    w + 5 * (size_t)RT_CHUNK, P.q_in_count, s->sort_tmp.p, &tmp_bytes, stream);
+      if (e != hipSuccess) return fail(RT_ERR_HIP, "radix sort failed: %s", hipGetErrorString(e));
+    }
+    e = (hipError_t)rt_launch_shade(s->dev, P, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
     if (k < levels) {
       int rc = drain_level(s, P, k + 1, levels, stream);
       if (rc != RT_OK) return rc;
@@ -448,6 +458,20 @@ static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream) {
   if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
   HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));
   uint32_t* counts = (uint32_t*)s->qcount.p;  // [0] = overflow flag, [k] = rays waiting at level k
+  {
+    // per-chunk trace workspace: t, id, key, key', idx, idx'  (6 x RT_CHUNK dwords) + sort scratch
+    if ((rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4)) != RT_OK) return rc;
+    size_t tmp_bytes = 0;
+    hipError_t se = (hipError_t)rt_sort_pairs(nullptr, nullptr, nullptr, nullptr, RT_CHUNK, nullptr, &tmp_bytes, stream);
+    if (se != hipSuccess) return fail(RT_ERR_HIP, "radix sort size query failed: %s", hipGetErrorString(se));
+    if ((rc = s->sort_tmp.ensure(tmp_bytes + 256)) != RT_OK) return rc;
+    uint32_t* w = (uint32_t*)s->trace_ws.p;
+    P.tr_t = (float*)w;
+    P.tr_id = (int32_t*)(w + (size_t)RT_CHUNK);
+    P.tr_key = w + 2 * (size_t)RT_CHUNK;
+    P.tr_idx = w + 4 * (size_t)RT_CHUNK;
+    P.sh_idx = w + 5 * (size_t)RT_CHUNK;
+  }
   P.acc = (long long*)s->acc.p;
   P.q_capacity = RT_QUEUE_CAP;
   P.q_overflow = counts;

@@ -102,6 +102,12 @@ struct RtDevParams {
   // nullptr = all super-tiles of the window
   const uint32_t* sup_list;
   uint32_t n_sup;
+  // secondary rays: trace -> sort by hit point -> shade (per queue chunk, indices relative to q_in_first)
+  float* tr_t;            // [chunk] hit distance
+  int32_t* tr_id;         // [chunk] canonical hit id, -1 miss
+  uint32_t* tr_key;       // [chunk] Morton key of the hit point (0xFFFFFFFF miss)
+  uint32_t* tr_idx;       // [chunk] identity permutation written by the trace kernel
+  const uint32_t* sh_idx; // [chunk] ray indices sorted by key (shade kernel)
 };
 
 #define RT_BLOCK_W 16u
@@ -113,5 +119,9 @@ struct RtDevParams {
 uint32_t rt_primary_pixels_per_wg(const RtDevParams& p);
 uint32_t rt_primary_total_wgs(const RtDevParams& p);
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
-int rt_launch_secondary(const RtDevScene& sc, const RtDevParams& p, void* stream);
+int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, void* stream);
+int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream);
+// rocPRIM radix sort of (key, value) pairs (rt_sort.hip); tmp == nullptr: only returns the temp size
+int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n,
+                  void* tmp, size_t* tmp_bytes, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);

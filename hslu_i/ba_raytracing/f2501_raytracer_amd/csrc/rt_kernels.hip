@@ -892,10 +892,12 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-template <bool CULL>
 #define RT_STASH_FIELDS 13u
+// PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
+template <bool CULL, bool PRE>
 __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
-                                              const RayIn& r, float* stash /* LDS: [RT_STASH_FIELDS][256] */) {
+                                              const RayIn& r, float* stash /* LDS: [RT_STASH_FIELDS][256] */,
+                                              Hit pre) {
   RayOut out;
   out.hit = false;
   out.t = 0.0f;
@@ -910,14 +912,16 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   bool alive = have && !has_nan(d);
   unsigned long long bal = __ballot(alive);
   if (!bal) return out;
-  // ray accounting: lanes entering cast_ray, by kind
-  wv.cnt_kind[0] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
-  wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
-  wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
-  wv.cnt_pass += 1;
-  wv.cnt_lanes += (unsigned long long)__popcll(bal);
-
-  Hit h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
+  Hit h = pre;
+  if (!PRE) {
+    // ray accounting: lanes entering cast_ray, by kind
+    wv.cnt_kind[0] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
+    wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_pass += 1;
+    wv.cnt_lanes += (unsigned long long)__popcll(bal);
+    h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
+  }
   bool hit = alive && h.id >= 0;
   out.hit = hit;
   out.t = h.t;
@@ -1211,7 +1215,10 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   r.kind = KIND_PRIMARY;
   r.pix = pix;
 
-  RayOut out = process_ray<CULL>(sc, P, wv, pix_on, r, lds_stash);
+  Hit none;
+  none.t = INFINITY;
+  none.id = -1;
+  RayOut out = process_ray<CULL, false>(sc, P, wv, pix_on, r, lds_stash, none);
 
   // ---- per-pixel accumulation of the samples ----------------------------------------------------------
   V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
@@ -1290,15 +1297,33 @@ __global__ __launch_bounds__(256, 4) void rt_primary_kernel(RtDevScene sc, RtDev
 }
 
 // ------------------------------------------------------------------------------------------------
-// secondary kernel: one thread per queued ray (reflection / refraction child of any depth)
+// secondary rays (reflection / refraction children of any depth), three steps per queue chunk:
+//   rt_trace_kernel   one thread per queued ray: nearest hit -> (t, id) + a 30-bit Morton key of the
+//                     hit point (misses get the largest key)
+//   radix sort        (key, ray index) pairs, rocPRIM device sort (rt_sort.hip)
+//   rt_shade_kernel   one thread per ray IN HIT-POINT ORDER: lighting, pixel accumulation, children
+// After a refraction through the glass spheres the hit points of neighbouring pixels are scattered over
+// the whole scene; shading them in queue order made every wavefront's shadow packets incoherent (7x
+// slower per shadow ray than primary hits).  Sorted by hit point, the 64 lanes of a wavefront shade
+// neighbouring surface points whatever pixel they belong to.  The image does not depend on the order
+// (integer pixel accumulation).
 // ------------------------------------------------------------------------------------------------
-template <bool CULL>
-__device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDevParams& P, float* lds_stash,
-                                               unsigned long long* lds_cnt) {
-  Wave wv;
-  wave_init(wv);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const bool have = i < P.q_in_count;
+__device__ __forceinline__ RayIn load_queued_ray(const RtDevParams& P, size_t j) {
+  float4 a = P.q_in[0 * (size_t)P.q_capacity + j];
+  float4 b = P.q_in[1 * (size_t)P.q_capacity + j];
+  float4 c = P.q_in[2 * (size_t)P.q_capacity + j];
+  RayIn r;
+  r.o = mk(a.x, a.y, a.z);
+  r.n_start = a.w;
+  r.d_raw = mk(b.x, b.y, b.z);
+  int dk = __float_as_int(b.w);
+  r.depth = dk >> 2;
+  r.kind = dk & 3;
+  r.Wt = mk(c.x, c.y, c.z);
+  r.pix = __float_as_uint(c.w);
+  return r;
+}
+__device__ __forceinline__ RayIn idle_ray() {
   RayIn r;
   r.o = mk(0, 0, 0);
   r.d_raw = mk(0, 0, 1);
@@ -1307,32 +1332,94 @@ __device__ __forceinline__ void secondary_body(const RtDevScene& sc, const RtDev
   r.depth = 1;
   r.kind = KIND_REFL;
   r.pix = 0;
-  if (have) {
-    const size_t j = (size_t)P.q_in_first + i;
-    float4 a = P.q_in[0 * (size_t)P.q_capacity + j];
-    float4 b = P.q_in[1 * (size_t)P.q_capacity + j];
-    float4 c = P.q_in[2 * (size_t)P.q_capacity + j];
-    r.o = mk(a.x, a.y, a.z);
-    r.n_start = a.w;
-    r.d_raw = mk(b.x, b.y, b.z);
-    int dk = __float_as_int(b.w);
-    r.depth = dk >> 2;
-    r.kind = dk & 3;
-    r.Wt = mk(c.x, c.y, c.z);
-    r.pix = __float_as_uint(c.w);
+  return r;
+}
+__device__ __forceinline__ uint32_t morton_expand10(uint32_t v) {
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+template <bool CULL>
+__device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevParams& P, unsigned long long* lds_cnt) {
+  Wave wv;
+  wave_init(wv);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool have = i < P.q_in_count;
+  RayIn r = idle_ray();
+  if (have) r = load_queued_ray(P, (size_t)P.q_in_first + i);
+  V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
+  bool alive = have && !has_nan(d);
+  unsigned long long bal = __ballot(alive);
+  Hit h;
+  h.t = INFINITY;
+  h.id = -1;
+  if (bal) {
+    wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_pass += 1;
+    wv.cnt_lanes += (unsigned long long)__popcll(bal);
+    h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
   }
-  RayOut out = process_ray<CULL>(sc, P, wv, have, r, lds_stash);
+  if (have) {
+    const bool hit = alive && h.id >= 0;
+    uint32_t key = 0xFFFFFFFFu;
+    if (hit) {
+      V3 p = fma_s(d, h.t, r.o);
+      // scene units are ~[0,1]; [-0.5, 1.5) x [-0.5, 1.5) x [-0.5, 2.0) covers both named scenes generously
+      uint32_t qx = (uint32_t)clampf((p.x + 0.5f) * 512.0f, 0.0f, 1023.0f);
+      uint32_t qy = (uint32_t)clampf((p.y + 0.5f) * 512.0f, 0.0f, 1023.0f);
+      uint32_t qz = (uint32_t)clampf((p.z + 0.5f) * 409.6f, 0.0f, 1023.0f);
+      key = morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2);
+    }
+    P.tr_t[i] = h.t;
+    P.tr_id[i] = hit ? h.id : -1;
+    P.tr_key[i] = key;
+    P.tr_idx[i] = i;
+  }
+  wave_flush(wv, P, 0ull, lds_cnt);
+}
+
+__global__ __launch_bounds__(256, 4) void rt_trace_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ unsigned long long lds_cnt[16];
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    trace_body<true>(sc, P, lds_cnt);
+  else
+    trace_body<false>(sc, P, lds_cnt);
+}
+
+template <bool CULL>
+__device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevParams& P, float* lds_stash,
+                                           unsigned long long* lds_cnt) {
+  Wave wv;
+  wave_init(wv);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  bool have = i < P.q_in_count;
+  RayIn r = idle_ray();
+  Hit h;
+  h.t = INFINITY;
+  h.id = -1;
+  if (have) {
+    const uint32_t j = P.sh_idx[i];  // i-th ray in hit-point order
+    h.t = P.tr_t[j];
+    h.id = P.tr_id[j];
+    have = h.id >= 0;                // misses sort to the end: whole wavefronts fall through
+    if (have) r = load_queued_ray(P, (size_t)P.q_in_first + j);
+  }
+  RayOut out = process_ray<CULL, true>(sc, P, wv, have, r, lds_stash, h);
   if (out.hit) acc_add(P, r.pix, out.contrib);
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
-__global__ __launch_bounds__(256, 4) void rt_secondary_kernel(RtDevScene sc, RtDevParams P) {
+__global__ __launch_bounds__(256, 4) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    secondary_body<true>(sc, P, lds_stash, lds_cnt);
+    shade_body<true>(sc, P, lds_stash, lds_cnt);
   else
-    secondary_body<false>(sc, P, lds_stash, lds_cnt);
+    shade_body<false>(sc, P, lds_stash, lds_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1392,10 +1479,17 @@ int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs
   return (int)hipGetLastError();
 }
 
-int rt_launch_secondary(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, void* stream) {
   uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
   if (n_wgs == 0) return 0;
-  hipLaunchKernelGGL(rt_secondary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  hipLaunchKernelGGL(rt_trace_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+  uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
+  if (n_wgs == 0) return 0;
+  hipLaunchKernelGGL(rt_shade_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
