@@ -173,6 +173,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if gather is not None:
+        # set-up, not a step: create the RCCL communicator / connections before anything is timed
+        with torch.cuda.stream(stream):
+            gather.run(fb, stream)
+        barrier()
     for _ in range(args.warmup):
         frame()
     barrier()
