@@ -56,6 +56,10 @@ class TileGather:
 
         self.world, self.rank = world, rank
         self.host_staging = host_staging  # rehearsal only: move the payload through gloo on the host
+        self.use_all_gather = False      # fallback if the backend lacks gather (decided on the first call)
+        self.all_buf = None
+        self.calls = 0
+        self.gather_error = None
         self.device = device
         comm_device = torch.device("cpu") if host_staging else device
         idx = [owned_pixel_indices(cfg, world, r) for r in range(world)]
@@ -76,7 +80,25 @@ class TileGather:
         n = self.counts[self.rank]
         torch.index_select(fb, 0, self.own_idx, out=self.send[:n])
         send = self.send.cpu() if self.host_staging else self.send
-        dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
+        if not self.use_all_gather:
+            try:
+                dist.gather(send, self.recv if self.rank == 0 else None, dst=0)
+            except (RuntimeError, NotImplementedError) as e:  # backend without gather: decided once, at set-up
+                if self.calls > 0:
+                    raise
+                self.use_all_gather = True
+                self.gather_error = repr(e)
+        if self.use_all_gather:
+            if self.all_buf is None:
+                self.all_buf = torch.zeros(self.world * self.max_len, dtype=torch.int32, device=send.device)
+            dist.all_gather_into_tensor(self.all_buf, send)
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    seg = self.all_buf[r * self.max_len: r * self.max_len + self.counts[r]]
+                    fb.index_copy_(0, self.all_idx[r], seg.to(self.device))
+            self.calls += 1
+            return fb
+        self.calls += 1
         if self.rank == 0:
             for r in range(1, self.world):
                 fb.index_copy_(0, self.all_idx[r], self.recv[r][: self.counts[r]].to(self.device))
