@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, force_all_gather=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,6 +36,7 @@ def _worker(rank, world, port, out_path):
     part, _, _ = oracle_lib.render(flat, cfg, n_ranks=world, rank=rank, n_threads=2)
     fb = torch.from_numpy(part.view(np.int32).copy())
     g = TileGather(cfg, world, rank, torch.device("cpu"))
+    g.use_all_gather = force_all_gather
     g.run(fb)
     if rank == 0:
         full, _, _ = oracle_lib.render(flat, cfg, n_threads=2)
@@ -52,4 +53,13 @@ def test_tile_gather_world_size_n(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got, full = np.load(out)
     assert (full != 0).sum() > 1000
+    assert np.array_equal(got, full)
+
+
+def test_tile_gather_all_gather_fallback(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    got, full = np.load(out)
     assert np.array_equal(got, full)
