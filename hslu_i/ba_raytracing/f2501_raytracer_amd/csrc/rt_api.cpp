@@ -75,6 +75,7 @@ struct rt_scene {
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
+  uint32_t chunk = 1u << 16;  // rays per secondary launch / primary batch of the current frame
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host;
   float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
@@ -389,8 +390,26 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
 // deepest level first, so level k+1 never holds more than the children of one chunk of level k
 // (<= 2 * RT_CHUNK = capacity).  Pixel sums use a fixed-point accumulator (order independent,
 // hence bit-reproducible), resolved to packed pixels by a last kernel.
-static const uint32_t RT_CHUNK = 1u << 21;       // rays per secondary launch / per primary batch
-static const uint32_t RT_QUEUE_CAP = 2u * RT_CHUNK;
+// Rays per secondary launch / per primary batch ("chunk").  Deep tree levels hold few rays, and a launch
+// costs at least the serial time of one wavefront (lights x N shadow traversals), so launches must be
+// BIG: with 2 Mi-ray chunks 60 % of config 4's frame went to launches of < 1 Mi rays running at
+// 20-700 ns/ray instead of 7 (config 4: 1797 ms; 64 Mi-ray chunks: 452 ms).  The chunk is the whole
+// frame's primary rays when that fits: a queue level costs 2 * chunk * 48 B, and all levels together are
+// kept under RT_QUEUE_BUDGET -- this is what 288 GB of HBM are for.  RT_CHUNK_LOG2 overrides.
+static const size_t RT_QUEUE_BUDGET = (size_t)96 << 30;
+static uint32_t choose_chunk(uint64_t primary_items, uint32_t levels) {
+  int lg = 16;
+  while (lg < 26 && (1ull << lg) < primary_items) lg++;
+  while (lg > 16 && (size_t)levels * 2u * ((size_t)1 << lg) * 48u > RT_QUEUE_BUDGET) lg--;
+  if (const char* e = getenv("RT_CHUNK_LOG2")) {
+    lg = atoi(e);
+    if (lg < 10) lg = 10;
+    if (lg > 26) lg = 26;
+  }
+  return 1u << lg;
+}
+#define RT_CHUNK (s->chunk)
+#define RT_QUEUE_CAP (2u * s->chunk)
 
 static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels, hipStream_t stream) {
   uint32_t n = 0;
@@ -447,6 +466,7 @@ static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream) {
   int rc;
   const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
   if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
+  s->chunk = choose_chunk((uint64_t)total_wgs * 256u, levels);
   const size_t npix = (size_t)P.width * P.height;
   if (s->acc_pixels != npix) {
     if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
