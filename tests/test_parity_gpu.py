@@ -326,3 +326,19 @@ def test_random_scene_shadows_only_dense():
                                      n_cloud_sets=8, cloud_seed=7)
     flat = random_scene(11, n_spheres=4, n_tris=2500, n_lights=4, cfg=cfg)
     compare(cfg, flat, (60, 50, 48, 40))
+
+
+def test_ray_streaming_with_tiny_chunks(monkeypatch):
+    """Forces many primary batches and multi-chunk queue levels (RT_CHUNK_LOG2 = 10 -> 1024 rays per
+    launch): the deepest-first drain and the queue-capacity invariant must give the same image."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing"], depth_override=5)
+    flat = scenes.test_scene(cfg).flatten()
+    win = (300, 200, 96, 64)
+    a_ref, p_ref, s_ref = gpu_render(cfg, flat, win)
+    monkeypatch.setenv("RT_CHUNK_LOG2", "10")
+    a, p, s_ = gpu_render(cfg, flat, win)
+    monkeypatch.delenv("RT_CHUNK_LOG2")
+    assert np.array_equal(a, a_ref) and np.array_equal(p["rgb"], p_ref["rgb"])
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
+        assert s_[k] == s_ref[k]
+    compare(cfg, flat, win)
