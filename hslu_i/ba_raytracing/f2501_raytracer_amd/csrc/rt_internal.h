@@ -110,8 +110,6 @@ struct RtDevParams {
   const uint32_t* sh_idx; // [chunk] ray indices sorted by key (shade kernel)
 };
 
-#define RT_BLOCK_W 16u
-#define RT_BLOCK_H 16u
 #define RT_QUEUE_PLANES 3u
 #define RT_COUNTER_REPLICAS 64u
 

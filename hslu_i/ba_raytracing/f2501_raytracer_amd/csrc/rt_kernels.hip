@@ -14,15 +14,18 @@
 //
 // Execution model (MI355X-first, nothing like the reference's rayon + 8-lane packets):
 //   * every ray is an independent work item.  rt_primary_kernel: one thread per (pixel, AA sample),
-//     a wavefront = the samples of a few adjacent pixels; rt_secondary_kernel: one thread per queued
-//     reflection / refraction ray.  Children are appended to per-level ray queues in HBM (SoA float4
-//     planes, one atomic per wavefront) that the host drains deepest level first; pixel sums of
-//     secondary rays use 64-bit fixed-point atomics (order independent, bit-reproducible);
+//     a wavefront = the samples of a few adjacent pixels; rt_trace_kernel / rt_shade_kernel: one
+//     thread per queued reflection / refraction ray (nearest hit, radix sort by hit point, shading in
+//     hit-point order).  Children are appended to per-level ray queues in HBM (SoA float4 planes, one
+//     atomic per wavefront) that the host drains deepest level first in frame-sized chunks; pixel sums
+//     of secondary rays use 64-bit fixed-point atomics (order independent, bit-reproducible);
+//   * soft shadows walk the BVH once per (wavefront, light): the N jittered shadow rays of a hit point
+//     share a candidate triangle list (beam-level conservative culling), kept in the lanes of a VGPR;
 //   * BVH traversal is WAVE-COOPERATIVE: the 64 rays of a wavefront walk the tree together.  The
 //     current node index is wave-uniform, node / triangle / sphere / light records are fetched with
 //     scalar loads (constant address space -> s_load_dwordx4/x16), and the traversal stack is ONE
-//     stack per wavefront kept in LDS, driven by __ballot votes; lanes whose ray misses a box are
-//     masked for that subtree;
+//     stack per wavefront kept in the 64 lanes of a VGPR, driven by __ballot votes; lanes whose ray
+//     misses a box are masked for that subtree;
 //   * a conservative, staged triangle pre-filter keeps the IEEE division of the literal test for
 //     the few triangles some lane can actually hit;
 //   * no MFMA: this is branchy fp32 intersection math, not a contraction.
@@ -40,7 +43,6 @@
 #include "rt_internal.h"
 
 #define RT_EPS 1.1920929e-7f
-#define RT_STACK_DEPTH 64  /* one VGPR's worth of lanes */
 
 // Diagnostic builds only (make ABLATE=n): RT_DOUBLE bit i repeats one component's arithmetic with an
 // opaque copy of its inputs, so the time delta of the build IS that component's share of the kernel
