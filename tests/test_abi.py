@@ -74,3 +74,31 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librt_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def _build_c_example(tmp_path):
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "c_abi_example"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_example.c"),
+                           "-L", lib_dir, "-lrt_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    return exe
+
+
+def test_c_example_links_against_the_abi(tmp_path):
+    """A plain C caller (what a Rust / cgo / JNI binding amounts to) compiles and links with nothing but
+    include/rt_hip.h and librt_hip.so; without a GPU it reports that and exits 0."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "pixels written" in out.stdout or "no HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_renders_on_the_gpu(tmp_path):
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "pixels written 7680 of 7680" in out.stdout
