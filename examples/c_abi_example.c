@@ -87,5 +87,6 @@ int main(void) {
          (unsigned long long)st.rays_shadow, sum, st.kernel_ms);
   rt_scene_destroy(scene);
   free(argb);
-  return st.pixels_written == (uint64_t)p.width * p.height ? 0 : 2;
+  /* pixels whose ray misses everything keep the caller's background, as in the reference */
+  return (st.pixels_written > 0 && st.rays_primary == (uint64_t)p.width * p.height) ? 0 : 2;
 }

@@ -51,6 +51,21 @@
 #define RT_DOUBLE 0
 #endif
 #define RT_OPAQUE(v) asm volatile("" : "+v"(v))
+// Diagnostic build (make PROFILE=1 -> librt_hip_prof.so): wave-level shader-clock timers (s_memtime) around
+// the regions of the light loop; their sums replace the work counters in rt_stats (tools/perf_ab.py --prof).
+#ifndef RT_PROFILE
+#define RT_PROFILE 0
+#endif
+#ifndef RT_SKIP
+#define RT_SKIP 0
+#endif
+#if RT_PROFILE == 1
+#define PROF_T() __builtin_readcyclecounter()
+#define PROF_ADD(W, i, t0) ((W).prof[i] += __builtin_readcyclecounter() - (t0))
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(W, i, t0) ((void)(t0))
+#endif
 
 namespace {
 
@@ -359,6 +374,10 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
 struct WaveCtx {
   // wave-level work counters (uniform)
   unsigned long long n_nodes, n_tris, s_nodes, s_tris, s_passes, n_exact, s_exact;
+#if RT_PROFILE
+  unsigned long long t_mark;
+  unsigned long long prof[7];  // 0 nearest hit, 1 candidate collection, 2 sample set-up, 3 spheres, 4 triangles, 5 lighting, 6 whole ray
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -503,7 +522,7 @@ struct CandList {
 
 template <bool CULL>
 __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
-                                                              float delta, uint32_t cand_cap) {
+                                                              float delta, float eps_d, uint32_t cand_cap) {
   CandList L;
   L.reg = 0;
   L.count = 0;
@@ -537,8 +556,17 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // A triangle is dropped for the whole beam when, with these slacks plus the rounding margin of the
   // per-sample test (2e-6 * Lp * B * E), u < 0, v < 0 or u + v >= 1 holds for EVERY sample and the sign
   // of det cannot change inside the beam.  Otherwise it stays a candidate (the per-sample test decides).
+  //
+  // Beam-level t rejection (the surface the hit point lies on, and everything behind it).  Sample j starts at
+  // so_j = fl(p + ld_j*eps_d), so with b_j = v1 - so_j and unit ld_j || D_j:
+  //   (X.b_j) sgn(det) = (X.b0) sgn(det) - eps_d |D_j.X| / |D_j| - (X.rho) sgn,   |rho_i| <= ulp(|p_i| + eps_d)
+  // and |D_j.X| / |D_j| >= (|dseg.X| - dslack) / Lp.  The literal test needs t > EPS; its pre-filter already
+  // treats (X.b_j) sgn < -G * sum|x_i b_j,i| as "certainly t <= 0" (tri_hit stage 3), so a triangle whose upper
+  // bound of the left side stays below that for every sample can never be accepted by any of them.
   const float eps_o = delta;  // delta already contains 2*eps_distance; used as a (generous) bound on |do| too
   const float lenp = len + delta;
+  const float t_push = 0.998f * eps_d * __builtin_amdgcn_rcpf(lenp);
+  const float p_ulp = 1.3e-7f * (fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + eps_d) + 2.5e-6f * eps_d;  // + G*eps_d (sum|x b_j| vs sum|x b0|) + direction rounding
   auto beam_rejects = [&](uint32_t slot) -> bool {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
     float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
@@ -560,6 +588,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
     float su = E2 * geo, sv = E1 * geo;
     bool rej = (ybs + su < 0.0f) | (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
+    float xbs = __uint_as_float(__float_as_uint(dot(x, b)) ^ sgn);
+    float st0 = __builtin_fmaf(fabsf(x.x), fabsf(b.x), __builtin_fmaf(fabsf(x.y), fabsf(b.y), fabsf(x.z) * fabsf(b.z)));
+    rej |= __builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack);
     return sign_known & rej;
   };
   const unsigned long long grp = __ballot(alive);
@@ -645,6 +676,11 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   S.opacity = 1.0f;
   S.filter = mk(1.0f, 1.0f, 1.0f);
   V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
+#if RT_PROFILE
+  RT_OPAQUE(d.x);
+  PROF_ADD(W, 2, W.t_mark);
+#endif
+  const unsigned long long t_sph = PROF_T();
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
     if (i < 32u && !((cand.spheres >> i) & 1u)) continue;  // culled for this (wavefront, light)
     float4 s = uload(&sc.spheres[i]);
@@ -671,6 +707,11 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     }
   }
   if (sc.n_triangles == 0) return S;
+#if RT_PROFILE
+  RT_OPAQUE(S.opacity);
+#endif
+  PROF_ADD(W, 3, t_sph);
+  const unsigned long long t_tri = PROF_T();
 
   auto test_tri = [&](uint32_t slot, bool lane_on) {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
@@ -711,6 +752,10 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)cand.reg, (int)c);
       test_tri(slot, alive);
     }
+#if RT_PROFILE
+    RT_OPAQUE(S.opacity);
+#endif
+    PROF_ADD(W, 4, t_tri);
     return S;
   }
 
@@ -826,6 +871,10 @@ __device__ __forceinline__ void wave_init(Wave& w) {
   w.ctx.n_nodes = w.ctx.n_tris = w.ctx.s_nodes = w.ctx.s_tris = w.ctx.s_passes = w.ctx.n_exact = w.ctx.s_exact = 0;
   w.cnt_kind[0] = w.cnt_kind[1] = w.cnt_kind[2] = 0;
   w.cnt_shadow = w.cnt_pass = w.cnt_lanes = 0;
+#if RT_PROFILE
+  for (int i = 0; i < 7; i++) w.ctx.prof[i] = 0;
+  w.ctx.t_mark = 0;
+#endif
 }
 
 // Statistics: the wavefronts of a workgroup add their counters in LDS, then 14 threads issue one global
@@ -838,9 +887,15 @@ __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, 
   if (threadIdx.x < RT_N_COUNTERS) lds_cnt[threadIdx.x] = 0ull;
   __syncthreads();
   if ((threadIdx.x & 63u) == 0) {
+#if RT_PROFILE
+    const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
+                                                 w.cnt_pass,    w.ctx.prof[6], w.ctx.prof[0],  w.ctx.prof[1], w.ctx.prof[2],
+                                                 w.ctx.prof[3], w.ctx.s_passes, w.ctx.prof[4], w.ctx.prof[5]};
+#else
     const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
                                                  w.cnt_pass,    w.cnt_lanes,   w.ctx.n_nodes,  w.ctx.n_tris, w.ctx.s_nodes,
                                                  w.ctx.s_tris,  w.ctx.s_passes, w.ctx.n_exact, w.ctx.s_exact};
+#endif
 #pragma unroll
     for (unsigned i = 0; i < RT_N_COUNTERS; i++)
       if (v[i]) atomicAdd(&lds_cnt[i], v[i]);
@@ -910,6 +965,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
   const bool stream = P.q_out != nullptr;
 
+  const unsigned long long t_all = PROF_T();
   V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
   bool alive = have && !has_nan(d);
   unsigned long long bal = __ballot(alive);
@@ -922,7 +978,12 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
     wv.cnt_pass += 1;
     wv.cnt_lanes += (unsigned long long)__popcll(bal);
+    const unsigned long long t_n = PROF_T();
     h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
+#if RT_PROFILE
+    RT_OPAQUE(h.t);
+#endif
+    PROF_ADD(W, 0, t_n);
   }
   bool hit = alive && h.id >= 0;
   out.hit = hit;
@@ -981,15 +1042,44 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     cand.reg = 0;
     cand.count = RT_CAND_OVERFLOW;
     cand.spheres = 0xFFFFFFFFu;
-    if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
+    if ((RT_SKIP & 4) && N > 1) {  // removal ablation: no candidate collection either
+      cand.count = 0;
+      cand.spheres = 0;
+    } else if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
-      cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.cand_cap);
+      const unsigned long long t_c = PROF_T();
+      cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.eps_distance, P.cand_cap);
+#if RT_PROFILE
+      RT_OPAQUE(cand.reg);
+#endif
+      PROF_ADD(W, 1, t_c);
+#if RT_SKIP  // removal ablation (timing only, wrong image): 1 no shadow sphere tests, 2 no shadow triangle tests
+      if (RT_SKIP & 1) cand.spheres = 0;
+      if (RT_SKIP & 2) cand.count = 0;
+#endif
+#if RT_PROFILE == 2  // histogram of (wavefront, light) candidate sets instead of timers
+      {
+        const uint32_t nsph = (uint32_t)__popc(cand.spheres & ((1u << (sc.n_spheres < 32u ? sc.n_spheres : 31u)) - 1u));
+        const bool ov = cand.count == RT_CAND_OVERFLOW;
+        W.prof[0] += (!ov && cand.count == 0 && nsph == 0) ? 1 : 0;   // nothing to test at all
+        W.prof[1] += (!ov && cand.count == 0 && nsph > 0) ? 1 : 0;    // spheres only
+        W.prof[2] += (!ov && cand.count >= 1 && cand.count <= 4) ? 1 : 0;
+        W.prof[3] += (!ov && cand.count >= 5 && cand.count <= 16) ? 1 : 0;
+        W.prof[4] += (!ov && cand.count > 16) ? 1 : 0;
+        W.prof[5] += ov ? 1 : 0;
+        W.prof[6] += nsph;
+      }
+#endif
     }
+    const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
     // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
     // the load latency hides under a whole shadow traversal
     V3 cnext = mk(0, 0, 0);
     if (N > 1 && hit) cnext = mk(cs[0], cs[1], cs[2]);
     for (uint32_t j = 0; j < N; j++) {
+#if RT_PROFILE
+      W.t_mark = PROF_T();
+#endif
       V3 lp = mk(L0.x, L0.y, L0.z);
       if (N > 1) {
         lp.x = L0.x + cnext.x * P.fw;  // light.rs:218
@@ -998,26 +1088,45 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         if (hit && j + 1 < N) cnext = mk(cs[3 * j + 3], cs[3 * j + 4], cs[3 * j + 5]);
       }
       V3 ltp = lp - sf.p;
-      V3 ld = normalize(ltp);
-      V3 so = sf.p + ld * epsv;
-      float tmax = mag(lp - so);
-      if (RT_DOUBLE & 16) {  // diagnostic: repeat the shadow-ray set-up arithmetic
-        V3 lp2 = lp;
-        RT_OPAQUE(lp2.x);
-        V3 ltp2 = lp2 - sf.p;
-        V3 ld2 = normalize(ltp2);
-        V3 so2 = sf.p + ld2 * epsv;
-        float tmax2 = mag(lp2 - so2);
-        V3 d2 = normalize(ld2);
-        BoxRay b2 = box_ray(so2, d2);
-        if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
-      }
       wv.cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
-      Shadow S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax, cand);
+      V3 ld;
+      float lmag;
+      Shadow S;
+      if (nothing) {
+        // no triangle and no sphere can touch any sample ray of this (wavefront, light): the shadow ray is
+        // known to arrive, so its origin / length / re-normalised direction (3 IEEE sqrt, 2 IEEE div) are not
+        // needed; what is left of ld and |ltp| only scales the colour
+        const float l2 = dot(ltp, ltp);
+        const float rs = __builtin_amdgcn_rsqf(l2);
+        ld = ltp * rs;
+        lmag = l2 * rs;
+        S.occluded = false;
+        S.opacity = 1.0f;
+        S.filter = mk(1.0f, 1.0f, 1.0f);
+        W.s_passes++;
+      } else {
+        lmag = mag(ltp);
+        ld = ltp * (1.0f / lmag);  // normalize(ltp)
+        V3 so = sf.p + ld * epsv;
+        float tmax = mag(lp - so);
+        if (RT_DOUBLE & 16) {  // diagnostic: repeat the shadow-ray set-up arithmetic
+          V3 lp2 = lp;
+          RT_OPAQUE(lp2.x);
+          V3 ltp2 = lp2 - sf.p;
+          V3 ld2 = normalize(ltp2);
+          V3 so2 = sf.p + ld2 * epsv;
+          float tmax2 = mag(lp2 - so2);
+          V3 d2 = normalize(ld2);
+          BoxRay b2 = box_ray(so2, d2);
+          if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
+        }
+        S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax, cand);
+      }
       bool reach = hit && !S.occluded;
       if (!__ballot(reach)) continue;
+      const unsigned long long t_l = PROF_T();
       // PointLight::calculate_contribution_at, light.rs:261-299
-      float dist = mag(ltp) + RT_EPS;  // same sqrt as normalize(ltp) above (CSE)
+      float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp) above
       float cosi = fast_div(dot(ltp, sf.n), dist);
       bool pos = cosi > 0.0f;
       float att = 0.95f * (RT_EPS + dist + dist * dist);
@@ -1053,8 +1162,13 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         light_color = light_color + (mcolor * Lc) * light_factor;
         if (has_spec) spec_color = spec_color + lc * spec_factor;
       }
+#if RT_PROFILE
+      RT_OPAQUE(light_color.x);
+#endif
+      PROF_ADD(W, 5, t_l);
     }
   }
+  PROF_ADD(W, 6, t_all);
   // ---- back from LDS -------------------------------------------------------------------------------
   V3 Wt;
   float a, n_start;

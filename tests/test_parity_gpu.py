@@ -235,7 +235,12 @@ def test_candidate_overflow_falls_back_to_per_sample_walk(monkeypatch):
     for cap in ("0", "3"):
         monkeypatch.setenv("RT_CAND_MAX", cap)
         a, p, s_ = gpu_render(cfg, flat, win)
-        assert np.array_equal(a, a_ref) and np.array_equal(p["rgb"], p_ref["rgb"])
+        # every occlusion decision is identical; the colour differs only by the rounding of the fast
+        # arrival path (sets with nothing to test skip the IEEE normalisation of the light direction)
+        assert np.array_equal(p["hit_id"], p_ref["hit_id"]) and np.array_equal(p["hit_t"], p_ref["hit_t"])
+        assert np.abs(p["rgb"] - p_ref["rgb"]).max() <= 2e-6
+        ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+        assert np.abs(ch(a) - ch(a_ref)).max() <= 1
         assert s_["rays_shadow"] == s_ref["rays_shadow"]
     monkeypatch.delenv("RT_CAND_MAX")
 

@@ -41,6 +41,9 @@ for spec in args or ["c3"]:
         flat = scenes.semesterbild(cfg).flatten()
     else:
         cfg, flat, _ = bench.build_workload(name)
+    if os.environ.get("RT_AB_LIGHTS"):  # cost model experiments: keep only the first k lights
+        import dataclasses
+        flat = dataclasses.replace(flat, lights=flat.lights[: int(os.environ["RT_AB_LIGHTS"])])
     ds = DeviceScene(flat, 0)
     p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank)
     fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
@@ -62,4 +65,19 @@ for spec in args or ["c3"]:
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
           f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
+    if os.environ.get("RT_HIP_LIB", "").endswith("_prof2.so"):
+        # make PROFILE=2 build: histogram of the (wavefront, light) candidate sets
+        h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
+             st.wave_shadow_tris_exact]
+        tot = max(1, sum(h))
+        names = ["empty", "spheres only", "1-4 tris", "5-16 tris", ">16 tris", "overflow"]
+        print(f"{'':28s} candidate sets: " + "  ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, h))
+              + f"  | spheres kept per set {st.wave_ray_lanes/tot:.2f}")
+    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof.so"):
+        # make PROFILE=1 build: the work counters carry summed wave-level shader-clock cycles per region
+        reg = dict(nearest=st.wave_nearest_nodes, collect=st.wave_nearest_tris, setup=st.wave_shadow_nodes,
+                   spheres=st.wave_shadow_tris, triangles=st.wave_nearest_tris_exact, lighting=st.wave_shadow_tris_exact)
+        whole = max(1, st.wave_ray_lanes)
+        print(f"{'':28s} region share of process_ray wave-cycles: " + "  ".join(f"{k} {100.0*v/whole:.1f}%" for k, v in reg.items())
+              + f"  | cycles/shadow pass {whole/sp:.0f}")
     ds.close()
