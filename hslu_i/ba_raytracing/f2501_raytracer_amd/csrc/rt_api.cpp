@@ -143,12 +143,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
   const uint32_t ns = d->n_spheres, nt = d->n_triangles;
   int rc;
   {
-    std::vector<float> sp(4 * (size_t)ns);
+    // {cx, cy, cz, r_sq} per sphere, then one float per sphere: an upper bound of the radius (candidate culling)
+    std::vector<float> sp(5 * (size_t)ns);
     for (uint32_t i = 0; i < ns; i++) {
       sp[4 * i + 0] = d->sphere_center[3 * i + 0];
       sp[4 * i + 1] = d->sphere_center[3 * i + 1];
       sp[4 * i + 2] = d->sphere_center[3 * i + 2];
       sp[4 * i + 3] = d->sphere_r_sq[i];
+      sp[4 * (size_t)ns + i] = std::sqrt(std::fabs(d->sphere_r_sq[i])) * (1.0f + 4e-7f);
     }
     if ((rc = upload(s->spheres, sp.data(), sp.size() * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->sphere_mat, d->sphere_material, (size_t)ns * 4)) != RT_OK) return bail(rc);

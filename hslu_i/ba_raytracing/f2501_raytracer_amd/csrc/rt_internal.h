@@ -10,7 +10,7 @@
 
 // ---- device-side scene layout (all arrays live in HBM, read-only during a render) -------------
 //
-// spheres      float4 {cx, cy, cz, r_sq}                      16 B / sphere
+// spheres      float4 {cx, cy, cz, r_sq}                      16 B / sphere, then float radius bound[n_spheres]
 // sphere_mat   uint32 material row
 // tri_isect    3 x float4 per triangle REFERENCE (BVH leaf order, n_slots entries):  48 B each
 //                {v1.xyz, e1.x} {e1.yz, e2.xy} {e2.z, x.xyz}   x = e1 x e2 (ray independent part of

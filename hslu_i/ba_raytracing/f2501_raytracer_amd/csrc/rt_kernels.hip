@@ -546,6 +546,22 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
+  // The 64 segments of a wavefront (a few neighbouring pixels, one light) nearly always point into the same
+  // octant.  Then the entry / exit plane of every axis is the same for all lanes and is picked with scalar
+  // selects on the node's SGPR copy; the inflation folds into the per-lane fma constants: 6 fma + max3 + min3
+  // per box instead of 6 fma + 6 min/max + 6 add + 4 min/max.
+  const V3 cn = noi - dl, cf = noi + dl;
+  auto box_uniform = [&](const float* lo, const float* hi, uint32_t nx, uint32_t ny, uint32_t nz, float& smin) {
+    const uint32_t ax = nx ? __float_as_uint(hi[0]) : __float_as_uint(lo[0]), bx = nx ? __float_as_uint(lo[0]) : __float_as_uint(hi[0]);
+    const uint32_t ay = ny ? __float_as_uint(hi[1]) : __float_as_uint(lo[1]), by = ny ? __float_as_uint(lo[1]) : __float_as_uint(hi[1]);
+    const uint32_t az = nz ? __float_as_uint(hi[2]) : __float_as_uint(lo[2]), bz = nz ? __float_as_uint(lo[2]) : __float_as_uint(hi[2]);
+    smin = fmaxf(fmaxf(__builtin_fmaf(__uint_as_float(ax), inv.x, cn.x), __builtin_fmaf(__uint_as_float(ay), inv.y, cn.y)),
+                 __builtin_fmaf(__uint_as_float(az), inv.z, cn.z));
+    float smax = fminf(fminf(__builtin_fmaf(__uint_as_float(bx), inv.x, cf.x), __builtin_fmaf(__uint_as_float(by), inv.y, cf.y)),
+                       __builtin_fmaf(__uint_as_float(bz), inv.z, cf.z));
+    float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
+    return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
+  };
   // Beam-level barycentric rejection.  Every sample ray j of this lane is (o_j, D_j) = (p + do, dseg + dd)
   // with |do| <= eps_o, |dd| <= delta (un-normalised direction; u and v do not depend on its length).
   // The literal numerators are linear in (o, D):
@@ -567,31 +583,41 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   const float lenp = len + delta;
   const float t_push = 0.998f * eps_d * __builtin_amdgcn_rcpf(lenp);
   const float p_ulp = 1.3e-7f * (fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + eps_d) + 2.5e-6f * eps_d;  // + G*eps_d (sum|x b_j| vs sum|x b0|) + direction rounding
-  auto beam_rejects = [&](uint32_t slot) -> bool {
+  // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
+  // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
+  auto beam_rejects_all = [&](uint32_t slot, bool lanes) -> bool {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
     float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
     float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
     V3 c1 = mk(-q0.w, -q1.x, -q1.y), c2 = mk(-q1.z, -q1.w, -q2.x), x = mk(q2.y, q2.z, q2.w);
     V3 b = mk(q0.x, q0.y, q0.z) - p;
-    V3 y = mk((c2.y * dseg.z) + (-c2.z * dseg.y), (c2.z * dseg.x) + (-c2.x * dseg.z), (c2.x * dseg.y) + (-c2.y * dseg.x));
-    V3 z = mk((dseg.y * c1.z) + (-dseg.z * c1.y), (dseg.z * c1.x) + (-dseg.x * c1.z), (dseg.x * c1.y) + (-dseg.y * c1.x));
     float det = dot(dseg, x);
-    float E1 = fabsf(c1.x) + fabsf(c1.y) + fabsf(c1.z), E2 = fabsf(c2.x) + fabsf(c2.y) + fabsf(c2.z);
     float X1 = fabsf(x.x) + fabsf(x.y) + fabsf(x.z);
     float B = fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + eps_o;
     float geo = __builtin_fmaf(delta, B, lenp * eps_o) + 2e-6f * lenp * B;  // per unit edge length
     float ad = fabsf(det);
     float dslack = __builtin_fmaf(delta, X1, 2e-6f * lenp * X1);
-    bool sign_known = ad > dslack * 1.001f;
+    bool open = lanes && !(ad > dslack * 1.001f);  // sign of det unknown inside the beam: cannot reject
     const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
-    float ybs = __uint_as_float(__float_as_uint(dot(y, b)) ^ sgn);
-    float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
-    float su = E2 * geo, sv = E1 * geo;
-    bool rej = (ybs + su < 0.0f) | (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
+    // t: the surface the hit point lies on, and everything behind it
     float xbs = __uint_as_float(__float_as_uint(dot(x, b)) ^ sgn);
     float st0 = __builtin_fmaf(fabsf(x.x), fabsf(b.x), __builtin_fmaf(fabsf(x.y), fabsf(b.y), fabsf(x.z) * fabsf(b.z)));
-    rej |= __builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack);
-    return sign_known & rej;
+    bool rej = __builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack);
+    if (!__ballot(lanes && (open || !rej))) return true;
+    // u
+    V3 y = mk((c2.y * dseg.z) + (-c2.z * dseg.y), (c2.z * dseg.x) + (-c2.x * dseg.z), (c2.x * dseg.y) + (-c2.y * dseg.x));
+    float E2 = fabsf(c2.x) + fabsf(c2.y) + fabsf(c2.z);
+    float ybs = __uint_as_float(__float_as_uint(dot(y, b)) ^ sgn);
+    float su = E2 * geo;
+    rej |= ybs + su < 0.0f;
+    if (!__ballot(lanes && (open || !rej))) return true;
+    // v, u + v
+    V3 z = mk((dseg.y * c1.z) + (-dseg.z * c1.y), (dseg.z * c1.x) + (-dseg.x * c1.z), (dseg.x * c1.y) + (-dseg.y * c1.x));
+    float E1 = fabsf(c1.x) + fabsf(c1.y) + fabsf(c1.z);
+    float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
+    float sv = E1 * geo;
+    rej |= (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
+    return !__ballot(lanes && (open || !rej));
   };
   const unsigned long long grp = __ballot(alive);
   if (!grp) return L;
@@ -599,6 +625,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // whose centre is farther than r + delta from that segment cannot be touched by any of them
   {
     uint32_t mask = 0;
+    const float* sph_rad = (const float*)(sc.spheres + sc.n_spheres);  // host-computed radius bounds
     const float inv_len2 = __builtin_amdgcn_rcpf(fmaxf(dot(dseg, dseg), 1e-30f));
     const uint32_t ns = sc.n_spheres < 32u ? sc.n_spheres : 32u;
     for (uint32_t i = 0; i < ns; i++) {
@@ -606,19 +633,30 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       V3 w = mk(sp4.x, sp4.y, sp4.z) - p;
       float sp = clampf(dot(w, dseg) * inv_len2, 0.0f, 1.0f);
       V3 q = w - dseg * sp;
-      float reach = __builtin_sqrtf(sp4.w) + delta;
+      float reach = uload(&sph_rad[i]) + delta;
       bool near = dot(q, q) <= reach * reach * 1.0002f + 1e-12f;
       if (__ballot(alive && near)) mask |= 1u << i;
     }
     L.spheres = mask | (sc.n_spheres > 32u ? 0xFFFFFFFFu : 0u);
   }
+  // direction octant of the wavefront (sign of inv = sign of dseg, -0 included)
+  const unsigned long long mx = __ballot(__float_as_uint(inv.x) >> 31) & grp, my = __ballot(__float_as_uint(inv.y) >> 31) & grp,
+                           mz = __ballot(__float_as_uint(inv.z) >> 31) & grp;
+  const bool octant_uniform = (mx == 0 || mx == grp) && (my == 0 || my == grp) && (mz == 0 || mz == grp);
+  const uint32_t neg_x = mx != 0, neg_y = my != 0, neg_z = mz != 0;
   uint32_t stk = 0, sp = 0, node = 0;
   for (;;) {
     const RtNode nd = uload(&sc.nodes[node]);
     W.s_nodes++;
     float tn0, tn1;
-    bool h0 = box(nd.lo0, nd.hi0, tn0);
-    bool h1 = box(nd.lo1, nd.hi1, tn1);
+    bool h0, h1;
+    if (octant_uniform) {
+      h0 = box_uniform(nd.lo0, nd.hi0, neg_x, neg_y, neg_z, tn0);
+      h1 = box_uniform(nd.lo1, nd.hi1, neg_x, neg_y, neg_z, tn1);
+    } else {
+      h0 = box(nd.lo0, nd.hi0, tn0);
+      h1 = box(nd.lo1, nd.hi1, tn1);
+    }
     const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & grp) : 0ull;
     const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & grp) : 0ull;
     // near-first order so that early occluders are tested first by every sample
@@ -639,7 +677,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
         }
         const bool in_leaf = (b >> lane_id) & 1ull;
         for (uint32_t k = 0; k < nn; k++) {
-          if (!__ballot(in_leaf && !beam_rejects(cc + k))) continue;  // no sample of any lane can hit it
+          if (beam_rejects_all(cc + k, in_leaf)) continue;  // no sample of any lane can hit it
           L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
           L.count++;
         }
@@ -1072,6 +1110,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #endif
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
+#if RT_PROFILE == 3
+    uint32_t set_occ = 0, set_tot = 0, set_filt = 0;
+#endif
     // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
     // the load latency hides under a whole shadow traversal
     V3 cnext = mk(0, 0, 0);
@@ -1123,6 +1164,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax, cand);
       }
       bool reach = hit && !S.occluded;
+#if RT_PROFILE == 3
+      set_occ += (uint32_t)__popcll(__ballot(hit && S.occluded));
+      set_tot += (uint32_t)__popcll(__ballot(hit));
+      set_filt += (uint32_t)__popcll(__ballot(hit && !S.occluded && S.opacity < 1.0f));
+#endif
       if (!__ballot(reach)) continue;
       const unsigned long long t_l = PROF_T();
       // PointLight::calculate_contribution_at, light.rs:261-299
@@ -1167,6 +1213,14 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #endif
       PROF_ADD(W, 5, t_l);
     }
+#if RT_PROFILE == 3  // outcome of the (wavefront, light) sets that had something to test
+    if (!nothing && set_tot) {
+      const bool tri = cand.count != 0;
+      const int cls = set_occ == 0 ? (set_filt ? 2 : 0) : (set_occ == set_tot ? 1 : 2);  // lit / umbra / mixed
+      W.prof[(tri ? 0 : 3) + cls] += 1;
+      W.prof[6] += 1;
+    }
+#endif
   }
   PROF_ADD(W, 6, t_all);
   // ---- back from LDS -------------------------------------------------------------------------------

@@ -65,7 +65,14 @@ for spec in args or ["c3"]:
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
           f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
-    if os.environ.get("RT_HIP_LIB", "").endswith("_prof2.so"):
+    if os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
+        # make PROFILE=3 build: outcome of the candidate sets that had something to test
+        h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
+             st.wave_shadow_tris_exact]
+        tot = max(1, sum(h))
+        names = ["tris: all lit", "tris: all occluded", "tris: mixed", "spheres only: all lit", "spheres only: all occluded", "spheres only: mixed"]
+        print(f"{'':28s} set outcomes: " + "  ".join(f"{n} {100.0*v/tot:.1f}%" for n, v in zip(names, h)))
+    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof2.so"):
         # make PROFILE=2 build: histogram of the (wavefront, light) candidate sets
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
              st.wave_shadow_tris_exact]
