@@ -258,7 +258,7 @@ __device__ __forceinline__ bool sphere_hit(float4 s, V3 o, V3 d, float& t_out) {
 // y, z, b and det_i are shared by both phases and computed exactly as the literal code does.
 #define RT_TRI_G 2e-6f
 __device__ __forceinline__ bool tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, bool lane_on, float tlimit,
-                                        float& t_out, unsigned long long& n_exact) {
+                                        float& t_out, uint32_t& n_exact) {
   V3 v1 = mk(q0.x, q0.y, q0.z);
   V3 c1 = mk(-q0.w, -q1.x, -q1.y);  // -e1
   V3 c2 = mk(-q1.z, -q1.w, -q2.x);  // -e2
@@ -373,7 +373,7 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
 
 struct WaveCtx {
   // wave-level work counters (uniform)
-  unsigned long long n_nodes, n_tris, s_nodes, s_tris, s_passes, n_exact, s_exact;
+  uint32_t n_nodes, n_tris, s_nodes, s_tris, s_passes, n_exact, s_exact;  // one ray per wavefront: 32 bits are plenty
 #if RT_PROFILE
   unsigned long long t_mark;
   unsigned long long prof[7];  // 0 nearest hit, 1 candidate collection, 2 sample set-up, 3 spheres, 4 triangles, 5 lighting, 6 whole ray
@@ -751,10 +751,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   PROF_ADD(W, 3, t_sph);
   const unsigned long long t_tri = PROF_T();
 
-  auto test_tri = [&](uint32_t slot, bool lane_on) {
-    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
-    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
-    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+  auto test_tri_q = [&](uint32_t slot, float4 q0, float4 q1, float4 q2, bool lane_on) {
     float t;
     bool h = tri_hit(q0, q1, q2, o, d, lane_on && !S.occluded, tmax, t, W.s_exact);
     if (RT_DOUBLE & 2) {
@@ -773,6 +770,12 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (h) shadow_accumulate(S, m, n, d);
     }
   };
+  auto test_tri = [&](uint32_t slot, bool lane_on) {
+    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
+    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
+    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+    test_tri_q(slot, q0, q1, q2, lane_on);
+  };
 
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     for (uint32_t s = 0; s < sc.n_slots; s++)
@@ -790,10 +793,6 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)cand.reg, (int)c);
       test_tri(slot, alive);
     }
-#if RT_PROFILE
-    RT_OPAQUE(S.opacity);
-#endif
-    PROF_ADD(W, 4, t_tri);
     return S;
   }
 
@@ -902,7 +901,7 @@ enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
 
 struct Wave {
   WaveCtx ctx;
-  unsigned long long cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes;
+  uint32_t cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes;
 };
 
 __device__ __forceinline__ void wave_init(Wave& w) {
@@ -1011,11 +1010,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   Hit h = pre;
   if (!PRE) {
     // ray accounting: lanes entering cast_ray, by kind
-    wv.cnt_kind[0] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
-    wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_kind[0] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
+    wv.cnt_kind[1] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFR));
     wv.cnt_pass += 1;
-    wv.cnt_lanes += (unsigned long long)__popcll(bal);
+    wv.cnt_lanes += (uint32_t)__popcll(bal);
     const unsigned long long t_n = PROF_T();
     h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
 #if RT_PROFILE
@@ -1129,7 +1128,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         if (hit && j + 1 < N) cnext = mk(cs[3 * j + 3], cs[3 * j + 4], cs[3 * j + 5]);
       }
       V3 ltp = lp - sf.p;
-      wv.cnt_shadow += (unsigned long long)__popcll(__ballot(hit));
+      wv.cnt_shadow += (uint32_t)__popcll(__ballot(hit));
       V3 ld;
       float lmag;
       Shadow S;
@@ -1448,7 +1447,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       }
     }
   }
-  wave_flush(wv, P, (unsigned long long)__popcll(__ballot(wrote)), lds_cnt);
+  wave_flush(wv, P, (uint32_t)__popcll(__ballot(wrote)), lds_cnt);
 }
 
 // __launch_bounds__(256, 4): 127 VGPRs, NO scratch.  Measured on MI355X, config 3 (this kernel):
@@ -1527,10 +1526,10 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
   h.t = INFINITY;
   h.id = -1;
   if (bal) {
-    wv.cnt_kind[1] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (unsigned long long)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_kind[1] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFR));
     wv.cnt_pass += 1;
-    wv.cnt_lanes += (unsigned long long)__popcll(bal);
+    wv.cnt_lanes += (uint32_t)__popcll(bal);
     h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
   }
   if (have) {

@@ -65,7 +65,13 @@ for spec in args or ["c3"]:
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
           f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
-    if os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
+    if os.environ.get("RT_HIP_LIB", "").endswith("_prof4.so"):
+        # make PROFILE=4 build: inside candidate collection (wave-level shader-clock cycles)
+        n_sets = max(1, st.wave_shadow_passes // max(1, cfg.point_light_multiplicator))
+        print(f"{'':28s} per collection: total {st.wave_nearest_tris_exact/n_sets:.0f} cycles = sphere mask {st.wave_nearest_nodes/n_sets:.0f} + node loop "
+              f"{st.wave_nearest_tris/n_sets:.0f} + leaf triangles {st.wave_shadow_nodes/n_sets:.0f}; nodes {st.wave_shadow_tris_exact/n_sets:.1f}, "
+              f"leaf triangles {st.wave_shadow_tris/n_sets:.1f}; whole ray {st.wave_ray_lanes/max(1, st.wave_ray_passes):.0f} cycles")
+    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
         # make PROFILE=3 build: outcome of the candidate sets that had something to test
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
              st.wave_shadow_tris_exact]
