@@ -579,10 +579,12 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // and |D_j.X| / |D_j| >= (|dseg.X| - dslack) / Lp.  The literal test needs t > EPS; its pre-filter already
   // treats (X.b_j) sgn < -G * sum|x_i b_j,i| as "certainly t <= 0" (tri_hit stage 3), so a triangle whose upper
   // bound of the left side stays below that for every sample can never be accepted by any of them.
-  const float eps_o = delta;  // delta already contains 2*eps_distance; used as a (generous) bound on |do| too
   const float lenp = len + delta;
-  const float t_push = 0.998f * eps_d * __builtin_amdgcn_rcpf(lenp);
-  const float p_ulp = 1.3e-7f * (fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + eps_d) + 2.5e-6f * eps_d;  // + G*eps_d (sum|x b_j| vs sum|x b0|) + direction rounding
+  const float rcp_lenp = __builtin_amdgcn_rcpf(lenp);
+  const float t_push = 0.998f * eps_d * rcp_lenp;
+  const float p_ulp = 1.3e-7f * (fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + eps_d) + 2.5e-6f * eps_d;
+  // (p_ulp also carries G*eps_d for sum|x b_j| vs sum|x b0| and the rounding of the unit direction)
+  const float eps_o = __builtin_fmaf(1.01f, eps_d, 2.0f * p_ulp);  // bound of |so_j - p|: the eps_d push along ld_j + rounding
   // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
   // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
   auto beam_rejects_all = [&](uint32_t slot, bool lanes) -> bool {
@@ -631,11 +633,20 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     for (uint32_t i = 0; i < ns; i++) {
       float4 sp4 = uload(&sc.spheres[i]);
       V3 w = mk(sp4.x, sp4.y, sp4.z) - p;
-      float sp = clampf(dot(w, dseg) * inv_len2, 0.0f, 1.0f);
+      const float wd = dot(w, dseg);
+      float sp = clampf(wd * inv_len2, 0.0f, 1.0f);
       V3 q = w - dseg * sp;
       float reach = uload(&sph_rad[i]) + delta;
       bool near = dot(q, q) <= reach * reach * 1.0002f + 1e-12f;
-      if (__ballot(alive && near)) mask |= 1u << i;
+      // Leaving rays: with v_j = so_j - centre and unit d_j, sphere_hit has no root >= 0 when cc_j = |v_j|^2 - r^2
+      // is positive by more than the rounding of disc = b^2 - 4 cc (b^2 <= 4 |v|^2) and d_j.v_j > 0.  Over the beam
+      // d_j.v0 >= (-w.dseg - delta |w|) / Lp =: amin and cc_j >= cc0 + 2 eps_d amin - rounding.  This is the sphere
+      // the hit point lies on (lit side) and every sphere behind the hit point.
+      const float wl2 = dot(w, w), w1 = fabsf(w.x) + fabsf(w.y) + fabsf(w.z);
+      const float amin = (-wd - delta * w1) * rcp_lenp;
+      const float cc_lo = (wl2 - sp4.w) + 1.98f * eps_d * amin - (6e-6f * wl2 + 4.0f * p_ulp * w1);
+      const bool leaving = (amin > 1e-6f * w1) && (cc_lo > 0.0f);
+      if (__ballot(alive && near && !leaving)) mask |= 1u << i;
     }
     L.spheres = mask | (sc.n_spheres > 32u ? 0xFFFFFFFFu : 0u);
   }
