@@ -551,14 +551,15 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // selects on the node's SGPR copy; the inflation folds into the per-lane fma constants: 6 fma + max3 + min3
   // per box instead of 6 fma + 6 min/max + 6 add + 4 min/max.
   const V3 cn = noi - dl, cf = noi + dl;
-  auto box_uniform = [&](const float* lo, const float* hi, uint32_t nx, uint32_t ny, uint32_t nz, float& smin) {
-    const uint32_t ax = nx ? __float_as_uint(hi[0]) : __float_as_uint(lo[0]), bx = nx ? __float_as_uint(lo[0]) : __float_as_uint(hi[0]);
-    const uint32_t ay = ny ? __float_as_uint(hi[1]) : __float_as_uint(lo[1]), by = ny ? __float_as_uint(lo[1]) : __float_as_uint(hi[1]);
-    const uint32_t az = nz ? __float_as_uint(hi[2]) : __float_as_uint(lo[2]), bz = nz ? __float_as_uint(lo[2]) : __float_as_uint(hi[2]);
-    smin = fmaxf(fmaxf(__builtin_fmaf(__uint_as_float(ax), inv.x, cn.x), __builtin_fmaf(__uint_as_float(ay), inv.y, cn.y)),
-                 __builtin_fmaf(__uint_as_float(az), inv.z, cn.z));
-    float smax = fminf(fminf(__builtin_fmaf(__uint_as_float(bx), inv.x, cf.x), __builtin_fmaf(__uint_as_float(by), inv.y, cf.y)),
-                       __builtin_fmaf(__uint_as_float(bz), inv.z, cf.z));
+  // (mask-and-xor on the bit patterns instead of ?: -- hipcc turns a uniform float select into v_mov + v_cndmask)
+  auto box_uniform = [&](const float* lo, const float* hi, uint32_t mx, uint32_t my, uint32_t mz, float& smin) {
+    const uint32_t lx = __float_as_uint(lo[0]), hx = __float_as_uint(hi[0]), tx = (lx ^ hx) & mx;
+    const uint32_t ly = __float_as_uint(lo[1]), hy = __float_as_uint(hi[1]), ty = (ly ^ hy) & my;
+    const uint32_t lz = __float_as_uint(lo[2]), hz = __float_as_uint(hi[2]), tz = (lz ^ hz) & mz;
+    smin = fmaxf(fmaxf(__builtin_fmaf(__uint_as_float(lx ^ tx), inv.x, cn.x), __builtin_fmaf(__uint_as_float(ly ^ ty), inv.y, cn.y)),
+                 __builtin_fmaf(__uint_as_float(lz ^ tz), inv.z, cn.z));
+    float smax = fminf(fminf(__builtin_fmaf(__uint_as_float(hx ^ tx), inv.x, cf.x), __builtin_fmaf(__uint_as_float(hy ^ ty), inv.y, cf.y)),
+                       __builtin_fmaf(__uint_as_float(hz ^ tz), inv.z, cf.z));
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
@@ -642,6 +643,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       // is positive by more than the rounding of disc = b^2 - 4 cc (b^2 <= 4 |v|^2) and d_j.v_j > 0.  Over the beam
       // d_j.v0 >= (-w.dseg - delta |w|) / Lp =: amin and cc_j >= cc0 + 2 eps_d amin - rounding.  This is the sphere
       // the hit point lies on (lit side) and every sphere behind the hit point.
+      if (!__ballot(alive && near)) continue;
       const float wl2 = dot(w, w), w1 = fabsf(w.x) + fabsf(w.y) + fabsf(w.z);
       const float amin = (-wd - delta * w1) * rcp_lenp;
       const float cc_lo = (wl2 - sp4.w) + 1.98f * eps_d * amin - (6e-6f * wl2 + 4.0f * p_ulp * w1);
@@ -654,7 +656,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   const unsigned long long mx = __ballot(__float_as_uint(inv.x) >> 31) & grp, my = __ballot(__float_as_uint(inv.y) >> 31) & grp,
                            mz = __ballot(__float_as_uint(inv.z) >> 31) & grp;
   const bool octant_uniform = (mx == 0 || mx == grp) && (my == 0 || my == grp) && (mz == 0 || mz == grp);
-  const uint32_t neg_x = mx != 0, neg_y = my != 0, neg_z = mz != 0;
+  // all-ones where the octant is negative along the axis (kept in SGPRs)
+  const uint32_t neg_x = __builtin_amdgcn_readfirstlane(mx != 0 ? 0xFFFFFFFFu : 0u), neg_y = __builtin_amdgcn_readfirstlane(my != 0 ? 0xFFFFFFFFu : 0u),
+                 neg_z = __builtin_amdgcn_readfirstlane(mz != 0 ? 0xFFFFFFFFu : 0u);
   uint32_t stk = 0, sp = 0, node = 0;
   for (;;) {
     const RtNode nd = uload(&sc.nodes[node]);
