@@ -537,20 +537,22 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   V3 dl = mk(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));  // box inflation in s units
   float send = 1.0f + (delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f;     // past the cloud centre
   float sbeg = -((delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f);
+  // entry / exit parameters with the inflation folded into the fma constants: cn = noi - dl, cf = noi + dl
+  const V3 cn = noi - dl, cf = noi + dl;
   auto box = [&](const float* lo, const float* hi, float& smin) {
-    float tx1 = __builtin_fmaf(lo[0], inv.x, noi.x), tx2 = __builtin_fmaf(hi[0], inv.x, noi.x);
-    float ty1 = __builtin_fmaf(lo[1], inv.y, noi.y), ty2 = __builtin_fmaf(hi[1], inv.y, noi.y);
-    float tz1 = __builtin_fmaf(lo[2], inv.z, noi.z), tz2 = __builtin_fmaf(hi[2], inv.z, noi.z);
-    smin = fmaxf(fmaxf(fminf(tx1, tx2) - dl.x, fminf(ty1, ty2) - dl.y), fminf(tz1, tz2) - dl.z);
-    float smax = fminf(fminf(fmaxf(tx1, tx2) + dl.x, fmaxf(ty1, ty2) + dl.y), fmaxf(tz1, tz2) + dl.z);
+    smin = fmaxf(fmaxf(fminf(__builtin_fmaf(lo[0], inv.x, cn.x), __builtin_fmaf(hi[0], inv.x, cn.x)),
+                       fminf(__builtin_fmaf(lo[1], inv.y, cn.y), __builtin_fmaf(hi[1], inv.y, cn.y))),
+                 fminf(__builtin_fmaf(lo[2], inv.z, cn.z), __builtin_fmaf(hi[2], inv.z, cn.z)));
+    float smax = fminf(fminf(fmaxf(__builtin_fmaf(lo[0], inv.x, cf.x), __builtin_fmaf(hi[0], inv.x, cf.x)),
+                             fmaxf(__builtin_fmaf(lo[1], inv.y, cf.y), __builtin_fmaf(hi[1], inv.y, cf.y))),
+                       fmaxf(__builtin_fmaf(lo[2], inv.z, cf.z), __builtin_fmaf(hi[2], inv.z, cf.z)));
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
   // The 64 segments of a wavefront (a few neighbouring pixels, one light) nearly always point into the same
   // octant.  Then the entry / exit plane of every axis is the same for all lanes and is picked with scalar
   // selects on the node's SGPR copy; the inflation folds into the per-lane fma constants: 6 fma + max3 + min3
-  // per box instead of 6 fma + 6 min/max + 6 add + 4 min/max.
-  const V3 cn = noi - dl, cf = noi + dl;
+  // per box instead of 12 fma + 6 min/max + 4 min/max.
   // (mask-and-xor on the bit patterns instead of ?: -- hipcc turns a uniform float select into v_mov + v_cndmask)
   auto box_uniform = [&](const float* lo, const float* hi, uint32_t mx, uint32_t my, uint32_t mz, float& smin) {
     const uint32_t lx = __float_as_uint(lo[0]), hx = __float_as_uint(hi[0]), tx = (lx ^ hx) & mx;
@@ -1001,7 +1003,7 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-#define RT_STASH_FIELDS 13u
+#define RT_STASH_FIELDS 9u
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
 template <bool CULL, bool PRE>
 __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
@@ -1043,16 +1045,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   out.id = hit ? h.id : -1;
   if (!__ballot(hit)) return out;
 
-  Surf sf;
-  sf.p = mk(0, 0, 0);
-  sf.n = mk(0, 0, 1);
-  sf.mat = 0;
-  if (hit) sf = surface_of(sc, h, r.o, d);
-  Mat m = load_mat(sc, sf.mat);
   {
     // Park what the light loop does not need in LDS (SoA, one dword per lane per field: conflict
-    // free).  The loop below runs lights x N shadow traversals; these 13 values would otherwise sit
-    // in VGPRs (or worse, in scratch = HBM traffic) for all of them.
+    // free), before the surface and material are fetched.  The loop below runs lights x N shadow
+    // traversals; these values would otherwise sit in VGPRs (or worse, in scratch = HBM traffic)
+    // for all of them.
     // a reflection child's weight carries atten(child.t), known only now (:722-726)
     float a0 = atten(h.t);
     V3 W0 = r.Wt;
@@ -1064,16 +1061,18 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     st[3 * 256] = a0;
     st[4 * 256] = r.n_start;
     st[5 * 256] = __int_as_float((r.depth << 2) | r.kind);
-    st[6 * 256] = m.metallic;
-    st[7 * 256] = m.ior;
-    st[8 * 256] = m.opacity;
-    st[9 * 256] = m.boost;
-    st[10 * 256] = m.transmissive ? 1.0f : 0.0f;
-    st[11 * 256] = h.t;
-    st[12 * 256] = __int_as_float(out.id);
+    st[7 * 256] = h.t;
+    st[8 * 256] = __int_as_float(out.id);
   }
-  const V3 mcolor = m.color;
-  const float mshin = m.shininess;
+  Surf sf;
+  sf.p = mk(0, 0, 0);
+  sf.n = mk(0, 0, 1);
+  sf.mat = 0;
+  if (hit) sf = surface_of(sc, h, r.o, d);
+  stash[threadIdx.x + 6 * 256] = __uint_as_float(sf.mat);  // the material row is simply read again after the loop (L2)
+  const Mat m_lit = load_mat(sc, sf.mat);
+  const V3 mcolor = m_lit.color;
+  const float mshin = m_lit.shininess;
   const uint32_t pixel = r.pix;
 
   // ---- calculate_lighting, raytracer_renderer.rs:731-874 ----------------------------------------
@@ -1241,23 +1240,24 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   V3 Wt;
   float a, n_start;
   int depth, kind;
+  Mat m;
   {
-    const float* st = stash + threadIdx.x;
+    // (opaque index: otherwise hipcc forwards the stored values to these loads, i.e. keeps them in
+    // registers or scratch through the whole light loop, which is what the stash is there to avoid)
+    uint32_t tix = threadIdx.x;
+    RT_OPAQUE(tix);
+    const float* st = stash + tix;
     Wt = mk(st[0 * 256], st[1 * 256], st[2 * 256]);
     a = st[3 * 256];
     n_start = st[4 * 256];
     int dk = __float_as_int(st[5 * 256]);
     depth = dk >> 2;
     kind = dk & 3;
-    m.color = mcolor;
-    m.shininess = mshin;
-    m.metallic = st[6 * 256];
-    m.ior = st[7 * 256];
-    m.opacity = st[8 * 256];
-    m.boost = st[9 * 256];
-    m.transmissive = st[10 * 256] != 0.0f;
-    out.t = st[11 * 256];
-    out.id = __float_as_int(st[12 * 256]);
+    uint32_t mat_row = __float_as_uint(st[6 * 256]);
+    RT_OPAQUE(mat_row);  // keeps hipcc from carrying the row's addresses through the loop (in scratch)
+    m = load_mat(sc, mat_row);
+    out.t = st[7 * 256];
+    out.id = __float_as_int(st[8 * 256]);
   }
   (void)kind;
   V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
