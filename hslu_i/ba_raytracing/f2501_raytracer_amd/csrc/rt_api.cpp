@@ -77,7 +77,7 @@ struct rt_scene {
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
   uint32_t chunk = 1u << 16;  // rays per secondary launch / primary batch of the current frame
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
-  std::vector<float> aa_host, cloud_host;
+  std::vector<float> aa_host, cloud_host, cloud_scaled;
   float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
 };
@@ -301,16 +301,23 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   P->n_cloud_sets = p->n_cloud_sets;
   if (P->light_mult > 1) {
     size_t n = (size_t)p->n_cloud_sets * P->light_mult * 3;
-    if (s->cloud_host.size() != n || memcmp(s->cloud_host.data(), p->cloud_sets, n * 4) != 0) {
-      if ((rc = s->cloud.ensure(n * 4)) != RT_OK) return rc;
-      s->cloud_host.assign(p->cloud_sets, p->cloud_sets + n);
+    const bool new_table = s->cloud_host.size() != n || memcmp(s->cloud_host.data(), p->cloud_sets, n * 4) != 0;
+    const bool new_scale = s->cloud_ball_f[0] != p->fw || s->cloud_ball_f[1] != p->fh || s->cloud_ball_f[2] != p->fd;
+    if (new_table || new_scale) {
+      // The device table holds the offsets already multiplied by (fw, fh, fd) (light.rs:218: the same IEEE
+      // single multiply the kernel would do, done once here), one float4 per sample position.
+      if ((rc = s->cloud.ensure(n / 3 * 16)) != RT_OK) return rc;
+      if (new_table) s->cloud_host.assign(p->cloud_sets, p->cloud_sets + n);
       s->cloud_ball[3] = -1.f;  // recompute the bounding ball
-      HIP_TRY(hipMemcpyAsync(s->cloud.p, s->cloud_host.data(), n * 4, hipMemcpyHostToDevice, stream));
-    }
-    P->cloud_sets = (const float*)s->cloud.p;
-    // bounding ball of the offsets cs * (fw, fh, fd) over all sets (cached with the table)
-    if (s->cloud_ball[3] < 0.f || s->cloud_ball_f[0] != p->fw || s->cloud_ball_f[1] != p->fh || s->cloud_ball_f[2] != p->fd) {
       s->cloud_ball_f[0] = p->fw, s->cloud_ball_f[1] = p->fh, s->cloud_ball_f[2] = p->fd;
+      const float f[3] = {p->fw, p->fh, p->fd};
+      s->cloud_scaled.assign(n / 3 * 4, 0.0f);
+      for (size_t i = 0; i < n; i++) s->cloud_scaled[i / 3 * 4 + i % 3] = s->cloud_host[i] * f[i % 3];
+      HIP_TRY(hipMemcpyAsync(s->cloud.p, s->cloud_scaled.data(), n / 3 * 16, hipMemcpyHostToDevice, stream));
+    }
+    P->cloud_sets = (const float4*)s->cloud.p;
+    // bounding ball of the offsets cs * (fw, fh, fd) over all sets (cached with the table)
+    if (s->cloud_ball[3] < 0.f || new_scale) {
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
       const float f[3] = {p->fw, p->fh, p->fd};
       for (size_t i = 0; i < n; i++) {

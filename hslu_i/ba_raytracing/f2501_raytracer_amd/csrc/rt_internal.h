@@ -71,7 +71,7 @@ struct RtDevParams {
   uint32_t aa_rays;          // 0 = no anti-aliasing (one centre ray)
   const float* aa_offsets;   // device, [aa_rays][2]
   uint32_t light_mult, cloud_seed, n_cloud_sets;
-  const float* cloud_sets;   // device, [n_sets][light_mult][3]
+  const float4* cloud_sets;  // device, [n_sets][light_mult] {dx*fw, dy*fh, dz*fd, 0}: pre-scaled light-cloud offsets
   // bounding ball of all cloud offsets (scene units): offset of its centre from the light position and
   // its radius (computed on the host over every set; 0 = unknown -> no candidate sharing)
   float cloud_centre[3];

@@ -1082,12 +1082,29 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     const float4 L0 = uload(&sc.lights[2 * l + 0]);
     const float4 L1 = uload(&sc.lights[2 * l + 1]);
     const V3 lc = mk(L1.x, L1.y, L1.z);
-    const float* cs = nullptr;
+    const float4* cs = nullptr;
     float lI = L0.w;
     if (N > 1) {
       uint32_t set = rt_cloud_hash(P.cloud_seed, pixel, l) % P.n_cloud_sets;
-      cs = P.cloud_sets + (size_t)set * N * 3u;
+      cs = P.cloud_sets + (size_t)set * N;
       lI = (1.0f / (float)N) * L0.w;
+    }
+    // Lights below the horizon of the hit point: the contribution is gated by diff = max(n.ld, 0) > 0
+    // (light.rs / :800-802), so a lane whose every sample direction has n.ld_j <= 0 adds nothing for this
+    // light whatever its shadow rays would find -- they are not traced (they still count in rays_shadow).
+    // n.D_j <= n.dc + delta |n|_1 over the cloud; the margin covers the fp32 rounding of n.ld_j.
+    bool use = hit;
+    {
+      const float dl = (N > 1) ? P.cloud_delta : 0.0f;
+      V3 dc = mk(L0.x, L0.y, L0.z) - sf.p;
+      if (N > 1) dc = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]) - sf.p;
+      const float n1 = fabsf(sf.n.x) + fabsf(sf.n.y) + fabsf(sf.n.z);
+      const float scale = fabsf(dc.x) + fabsf(dc.y) + fabsf(dc.z) + fabsf(sf.p.x) + fabsf(sf.p.y) + fabsf(sf.p.z) + 1.0f;
+      use = hit && (dot(sf.n, dc) + n1 * __builtin_fmaf(4e-6f, scale, dl) > 0.0f);
+    }
+    if (!__ballot(use)) {
+      wv.cnt_shadow += N * (uint32_t)__popcll(__ballot(hit));
+      continue;
     }
     CandList cand;
     cand.reg = 0;
@@ -1099,7 +1116,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     } else if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
       const unsigned long long t_c = PROF_T();
-      cand = collect_light_candidates<CULL>(sc, W, hit, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.eps_distance, P.cand_cap);
+      cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.eps_distance, P.cand_cap);
 #if RT_PROFILE
       RT_OPAQUE(cand.reg);
 #endif
@@ -1128,18 +1145,18 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #endif
     // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
     // the load latency hides under a whole shadow traversal
-    V3 cnext = mk(0, 0, 0);
-    if (N > 1 && hit) cnext = mk(cs[0], cs[1], cs[2]);
+    float4 cnext = make_float4(0, 0, 0, 0);
+    if (N > 1 && use) cnext = cs[0];
     for (uint32_t j = 0; j < N; j++) {
 #if RT_PROFILE
       W.t_mark = PROF_T();
 #endif
       V3 lp = mk(L0.x, L0.y, L0.z);
       if (N > 1) {
-        lp.x = L0.x + cnext.x * P.fw;  // light.rs:218
-        lp.y = L0.y + cnext.y * P.fh;
-        lp.z = L0.z + cnext.z * P.fd;
-        if (hit && j + 1 < N) cnext = mk(cs[3 * j + 3], cs[3 * j + 4], cs[3 * j + 5]);
+        lp.x = L0.x + cnext.x;  // light.rs:218; the table holds offset * (fw, fh, fd)
+        lp.y = L0.y + cnext.y;
+        lp.z = L0.z + cnext.z;
+        if (use && j + 1 < N) cnext = cs[j + 1];
       }
       V3 ltp = lp - sf.p;
       wv.cnt_shadow += (uint32_t)__popcll(__ballot(hit));
@@ -1174,13 +1191,13 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
           BoxRay b2 = box_ray(so2, d2);
           if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
         }
-        S = shadow_ray<CULL>(sc, P, W, hit, so, ld, tmax, cand);
+        S = shadow_ray<CULL>(sc, P, W, use, so, ld, tmax, cand);
       }
-      bool reach = hit && !S.occluded;
+      bool reach = use && !S.occluded;
 #if RT_PROFILE == 3
-      set_occ += (uint32_t)__popcll(__ballot(hit && S.occluded));
-      set_tot += (uint32_t)__popcll(__ballot(hit));
-      set_filt += (uint32_t)__popcll(__ballot(hit && !S.occluded && S.opacity < 1.0f));
+      set_occ += (uint32_t)__popcll(__ballot(use && S.occluded));
+      set_tot += (uint32_t)__popcll(__ballot(use));
+      set_filt += (uint32_t)__popcll(__ballot(use && !S.occluded && S.opacity < 1.0f));
 #endif
       if (!__ballot(reach)) continue;
       const unsigned long long t_l = PROF_T();
