@@ -335,6 +335,15 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     }
     memcpy(P->cloud_centre, s->cloud_ball, 12);
     P->cloud_delta = s->cloud_ball[3];
+    {
+      const float e = p->eps_distance;
+      P->beam_delta = P->cloud_delta + 2.0f * e;
+      P->beam_delta_e5 = P->beam_delta + 1e-5f;
+      P->beam_eps_push = 0.998f * e;
+      P->beam_eps_ulp = (1.3e-7f + 2.5e-6f) * e;
+      P->beam_eps_o = 1.01f * e + 2.0f * P->beam_eps_ulp;
+      P->beam_eps_198 = 1.98f * e;
+    }
     P->cand_cap = 64;
     if (const char* e = getenv("RT_CAND_MAX")) P->cand_cap = (uint32_t)atoi(e) > 64u ? 64u : (uint32_t)atoi(e);  // experiments
   }

@@ -71,6 +71,9 @@ struct RtDevParams {
   uint32_t aa_rays;          // 0 = no anti-aliasing (one centre ray)
   const float* aa_offsets;   // device, [aa_rays][2]
   uint32_t light_mult, cloud_seed, n_cloud_sets;
+  // host-computed constants of the soft-shadow beam tests (uniform float arithmetic would sit in VGPRs):
+  // delta = cloud_delta + 2 eps, delta + 1e-5, 0.998 eps, (1.3e-7 + 2.5e-6) eps, 1.01 eps + 2 * that, 1.98 eps
+  float beam_delta, beam_delta_e5, beam_eps_push, beam_eps_ulp, beam_eps_o, beam_eps_198;
   const float4* cloud_sets;  // device, [n_sets][light_mult] {dx*fw, dy*fh, dz*fd, 0}: pre-scaled light-cloud offsets
   // bounding ball of all cloud offsets (scene units): offset of its centre from the light position and
   // its radius (computed on the host over every set; 0 = unknown -> no candidate sharing)

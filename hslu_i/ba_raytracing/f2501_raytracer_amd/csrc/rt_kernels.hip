@@ -522,7 +522,8 @@ struct CandList {
 
 template <bool CULL>
 __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
-                                                              float delta, float eps_d, uint32_t cand_cap) {
+                                                              const RtDevParams& P, uint32_t cand_cap) {
+  const float delta = P.beam_delta;
   CandList L;
   L.reg = 0;
   L.count = 0;
@@ -535,8 +536,8 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
               clampf(__builtin_amdgcn_rcpf(dseg.z), -1e30f, 1e30f));
   V3 noi = mk(-(p.x * inv.x), -(p.y * inv.y), -(p.z * inv.z));
   V3 dl = mk(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));  // box inflation in s units
-  float send = 1.0f + (delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f;     // past the cloud centre
-  float sbeg = -((delta + 1e-5f) * __builtin_amdgcn_rcpf(len) + 1e-5f);
+  float send = 1.0f + P.beam_delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f;  // past the cloud centre
+  float sbeg = -(P.beam_delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f);
   // entry / exit parameters with the inflation folded into the fma constants: cn = noi - dl, cf = noi + dl
   const V3 cn = noi - dl, cf = noi + dl;
   auto box = [&](const float* lo, const float* hi, float& smin) {
@@ -584,10 +585,10 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // bound of the left side stays below that for every sample can never be accepted by any of them.
   const float lenp = len + delta;
   const float rcp_lenp = __builtin_amdgcn_rcpf(lenp);
-  const float t_push = 0.998f * eps_d * rcp_lenp;
-  const float p_ulp = 1.3e-7f * (fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + eps_d) + 2.5e-6f * eps_d;
+  const float t_push = P.beam_eps_push * rcp_lenp;
+  const float p_ulp = __builtin_fmaf(1.3e-7f, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)), P.beam_eps_ulp);  // 1.3e-7 (|p| + eps) + 2.5e-6 eps
   // (p_ulp also carries G*eps_d for sum|x b_j| vs sum|x b0| and the rounding of the unit direction)
-  const float eps_o = __builtin_fmaf(1.01f, eps_d, 2.0f * p_ulp);  // bound of |so_j - p|: the eps_d push along ld_j + rounding
+  const float eps_o = __builtin_fmaf(2.6e-7f, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)), P.beam_eps_o);  // 1.01 eps + 2 p_ulp >= |so_j - p|
   // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
   // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
   auto beam_rejects_all = [&](uint32_t slot, bool lanes) -> bool {
@@ -648,7 +649,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       if (!__ballot(alive && near)) continue;
       const float wl2 = dot(w, w), w1 = fabsf(w.x) + fabsf(w.y) + fabsf(w.z);
       const float amin = (-wd - delta * w1) * rcp_lenp;
-      const float cc_lo = (wl2 - sp4.w) + 1.98f * eps_d * amin - (6e-6f * wl2 + 4.0f * p_ulp * w1);
+      const float cc_lo = (wl2 - sp4.w) + P.beam_eps_198 * amin - (6e-6f * wl2 + 4.0f * p_ulp * w1);
       const bool leaving = (amin > 1e-6f * w1) && (cc_lo > 0.0f);
       if (__ballot(alive && near && !leaving)) mask |= 1u << i;
     }
@@ -1003,7 +1004,7 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-#define RT_STASH_FIELDS 9u
+#define RT_STASH_FIELDS 10u
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
 template <bool CULL, bool PRE>
 __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
@@ -1063,6 +1064,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     st[5 * 256] = __int_as_float((r.depth << 2) | r.kind);
     st[7 * 256] = h.t;
     st[8 * 256] = __int_as_float(out.id);
+    st[9 * 256] = __uint_as_float(r.pix);
   }
   Surf sf;
   sf.p = mk(0, 0, 0);
@@ -1073,7 +1075,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   const Mat m_lit = load_mat(sc, sf.mat);
   const V3 mcolor = m_lit.color;
   const float mshin = m_lit.shininess;
-  const uint32_t pixel = r.pix;
 
   // ---- calculate_lighting, raytracer_renderer.rs:731-874 ----------------------------------------
   V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
@@ -1085,6 +1086,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     const float4* cs = nullptr;
     float lI = L0.w;
     if (N > 1) {
+      uint32_t tix = threadIdx.x;
+      RT_OPAQUE(tix);  // a real LDS read per light instead of a register held through the loop
+      const uint32_t pixel = __float_as_uint(stash[9u * 256u + tix]);
       uint32_t set = rt_cloud_hash(P.cloud_seed, pixel, l) % P.n_cloud_sets;
       cs = P.cloud_sets + (size_t)set * N;
       lI = (1.0f / (float)N) * L0.w;
@@ -1116,7 +1120,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     } else if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
       const unsigned long long t_c = PROF_T();
-      cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P.cloud_delta + 2.0f * P.eps_distance, P.eps_distance, P.cand_cap);
+      cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P, P.cand_cap);
 #if RT_PROFILE
       RT_OPAQUE(cand.reg);
 #endif
@@ -1257,6 +1261,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   V3 Wt;
   float a, n_start;
   int depth, kind;
+  uint32_t pixel;
   Mat m;
   {
     // (opaque index: otherwise hipcc forwards the stored values to these loads, i.e. keeps them in
@@ -1275,6 +1280,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     m = load_mat(sc, mat_row);
     out.t = st[7 * 256];
     out.id = __float_as_int(st[8 * 256]);
+    pixel = __float_as_uint(st[9 * 256]);
   }
   (void)kind;
   V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
@@ -1380,25 +1386,37 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   wave_init(wv);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
   const uint32_t n_samples = aa ? P.aa_rays : 1u;
-  const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
-  const uint32_t slot = threadIdx.x / n_samples;
-  const uint32_t k = threadIdx.x - slot * n_samples;
-  // workgroup -> 16x16 super-tile (through the list of super-tiles this rank owns, if any) -> pixel
-  const uint32_t st_x = (P.win_w + 15u) / 16u;
-  const uint32_t wgs_per_sup = (256u + ppw - 1u) / ppw;
-  const uint32_t wg = P.batch_first_wg + blockIdx.x;
-  const uint32_t sup_slot = wg / wgs_per_sup;
-  const uint32_t sup = P.sup_list ? uload(&P.sup_list[sup_slot]) : sup_slot;
-  const uint32_t in_sup = (wg - sup_slot * wgs_per_sup) * ppw + slot;
-  const bool lane_used = (slot < ppw) && (in_sup < 256u);
-  const uint32_t t4 = (in_sup >> 4) & 15u, p4 = in_sup & 15u;
-  const uint32_t lx = (sup % st_x) * 16u + (t4 & 3u) * 4u + (p4 & 3u);
-  const uint32_t ly = (sup / st_x) * 16u + (t4 >> 2) * 4u + (p4 >> 2);
-  const uint32_t gx = P.win_x0 + lx, gy = P.win_y0 + ly;
-  bool pix_on = lane_used && (lx < P.win_w) && (ly < P.win_h);
-  if (pix_on && P.n_ranks > 1) pix_on = rt_tile_owner(gx / P.tile_size, gy / P.tile_size, P.n_ranks) == P.rank;
-
-  const uint32_t pix = gy * P.width + gx;
+  // thread -> (pixel, AA sample): workgroup -> 16x16 super-tile (through the list of super-tiles this rank
+  // owns, if any) -> 4x4 tile -> pixel.  Evaluated twice (before the ray and again for the accumulation) so
+  // that nothing of it has to survive the light loops in registers.
+  struct PixelMap {
+    uint32_t slot, k, gx, gy, pix;
+    bool on;
+  };
+  auto map_thread = [&](uint32_t tid) {
+    PixelMap m;
+    const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
+    m.slot = tid / n_samples;
+    m.k = tid - m.slot * n_samples;
+    const uint32_t st_x = (P.win_w + 15u) / 16u;
+    const uint32_t wgs_per_sup = (256u + ppw - 1u) / ppw;
+    const uint32_t wg = P.batch_first_wg + blockIdx.x;
+    const uint32_t sup_slot = wg / wgs_per_sup;
+    const uint32_t sup = P.sup_list ? uload(&P.sup_list[sup_slot]) : sup_slot;
+    const uint32_t in_sup = (wg - sup_slot * wgs_per_sup) * ppw + m.slot;
+    const bool lane_used = (m.slot < ppw) && (in_sup < 256u);
+    const uint32_t t4 = (in_sup >> 4) & 15u, p4 = in_sup & 15u;
+    const uint32_t lx = (sup % st_x) * 16u + (t4 & 3u) * 4u + (p4 & 3u);
+    const uint32_t ly = (sup / st_x) * 16u + (t4 >> 2) * 4u + (p4 >> 2);
+    m.gx = P.win_x0 + lx, m.gy = P.win_y0 + ly;
+    m.on = lane_used && (lx < P.win_w) && (ly < P.win_h);
+    if (m.on && P.n_ranks > 1) m.on = rt_tile_owner(m.gx / P.tile_size, m.gy / P.tile_size, P.n_ranks) == P.rank;
+    m.pix = m.gy * P.width + m.gx;
+    return m;
+  };
+  const PixelMap pm = map_thread(threadIdx.x);
+  const bool pix_on = pm.on;
+  const uint32_t gx = pm.gx, gy = pm.gy, k = pm.k;
   const float x = (float)gx * P.fw;  // renderer/mod.rs:176-180
   const float y = (float)gy * P.fh;
   const V3 coords = mk(x, y, 0.0f);
@@ -1414,7 +1432,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   r.Wt = mk(scale, scale, scale);  // the sample's 1/total_rays weight rides along the whole tree
   r.depth = -1;
   r.kind = KIND_PRIMARY;
-  r.pix = pix;
+  r.pix = pm.pix;
 
   Hit none;
   none.t = INFINITY;
@@ -1424,13 +1442,17 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   // ---- per-pixel accumulation of the samples ----------------------------------------------------------
   V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
   lds_rgbh[threadIdx.x] = make_float4(cs.x, cs.y, cs.z, out.hit ? 1.0f : 0.0f);
-  if (k == 0 && pix_on) {
+  uint32_t tid2 = threadIdx.x;
+  RT_OPAQUE(tid2);  // keeps hipcc from carrying the first mapping through process_ray
+  const PixelMap pm2 = map_thread(tid2);
+  const uint32_t pix = pm2.pix, slot = pm2.slot;
+  if (pm2.k == 0 && pm2.on) {
     if (P.aux_hit_id) P.aux_hit_id[pix] = out.id;
     if (P.aux_hit_t && out.id >= 0) P.aux_hit_t[pix] = out.t;
   }
   __syncthreads();
   bool wrote = false;
-  if (k == 0 && pix_on) {
+  if (pm2.k == 0 && pm2.on) {
     const float4* s = lds_rgbh + slot * n_samples;
     V3 color;
     bool any = false;
