@@ -156,9 +156,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if ((rc = upload(s->sphere_mat, d->sphere_material, (size_t)ns * 4)) != RT_OK) return bail(rc);
   }
   RtBvh bvh;
+  std::vector<uint8_t> no_split(nt, 0);  // = transmissive
   {
     // transmissive triangles must be referenced exactly once (their shadow contributions add up)
-    std::vector<uint8_t> no_split(nt, 0);
     for (uint32_t i = 0; i < nt; i++) {
       const float* r = d->materials + (size_t)d->tri_material[i] * RT_MATERIAL_STRIDE;
       no_split[i] = (r[RT_MAT_HAS_OPACITY] != 0.0f && !(std::fabs(r[RT_MAT_OPACITY]) <= 1.1920929e-7f)) ? 1 : 0;
@@ -197,7 +197,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     if ((rc = upload(s->tri_isect, isect.data(), isect.size() * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->tri_shade, shade.data(), shade.size() * 4)) != RT_OK) return bail(rc);
-    if ((rc = upload(s->tri_id, bvh.tri_order.data(), (size_t)n_slots * 4)) != RT_OK) return bail(rc);
+    std::vector<uint32_t> ids(bvh.tri_order);
+    for (uint32_t slot = 0; slot < n_slots; slot++)
+      if (no_split[ids[slot] & ~RT_TRI_DUPLICATE]) ids[slot] |= RT_TRI_TRANSMISSIVE;
+    if ((rc = upload(s->tri_id, ids.data(), (size_t)n_slots * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
   }
   {

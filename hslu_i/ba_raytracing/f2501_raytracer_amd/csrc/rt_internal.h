@@ -36,6 +36,8 @@ static_assert(sizeof(RtNode) == 64, "node must be 64 bytes");
 
 #define RT_NODE_EMPTY 0xFFFFFFFFu  // c* value of an absent child (box is inverted, never hit)
 #define RT_TRI_DUPLICATE 0x80000000u  // tri_id flag: not the first reference of its triangle (slot order)
+#define RT_TRI_TRANSMISSIVE 0x40000000u  // tri_id flag (device copy): the triangle's material lets light through
+#define RT_TRI_INDEX_MASK 0x3FFFFFFFu
 
 struct RtBvh {
   std::vector<RtNode> nodes;        // nodes[0] is the root

@@ -421,7 +421,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       }
     }
     if (__ballot(h)) {
-      int id = tri_base + (int)(uload(&sc.tri_id[slot]) & ~RT_TRI_DUPLICATE);
+      int id = tri_base + (int)(uload(&sc.tri_id[slot]) & RT_TRI_INDEX_MASK);
       if (h && (t < best.t || (t == best.t && id > best.id))) {
         best.t = t;
         best.id = id;
@@ -518,6 +518,7 @@ struct CandList {
   uint32_t reg;     // lane i of this VGPR = i-th candidate triangle slot (wave-level list)
   uint32_t count;   // uniform; RT_CAND_OVERFLOW = not usable, walk the BVH per sample instead
   uint32_t spheres; // uniform bit mask: sphere i (< 32) may be touched by some sample ray of some lane
+  unsigned long long umbra;  // uniform lane mask: every sample ray of the lane certainly hits one opaque triangle
 };
 
 template <bool CULL>
@@ -528,6 +529,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   L.reg = 0;
   L.count = 0;
   L.spheres = 0xFFFFFFFFu;
+  L.umbra = 0ull;
   const uint32_t lane_id = threadIdx.x & 63u;
   // parametric segment x(s) = p + s*(c - p), s in [0, 1]
   V3 dseg = c - p;
@@ -623,7 +625,26 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
     float sv = E1 * geo;
     rej |= (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
-    return !__ballot(lanes && (open || !rej));
+    const unsigned long long keep = __ballot(lanes && (open || !rej));
+    if (!keep) return true;
+    // Umbra: the triangle is opaque and EVERY sample ray of the lane hits it between origin and light -- the
+    // literal test would accept it for each j (u_j, v_j >= 0, u_j + v_j < 1, EPS < t_j <= tmax_j, |det_j| > EPS,
+    // all by margins that cover the rounding of the literal sequence), so the lane is occluded for this light
+    // whatever else lies on the way: none of its samples needs to be traced.
+    if (!CULL && !(uload(&sc.tri_id[slot]) & RT_TRI_TRANSMISSIVE)) {
+      const float dlo = ad - dslack;
+      const float r_hi = lenp * __builtin_amdgcn_rcpf(dlo) * 1.00001f;                 // >= |D_j| / |D_j.X|
+      const float r_lo = (len - delta) * __builtin_amdgcn_rcpf(ad + dslack) * 0.99999f;  // <= |D_j| / |D_j.X|
+      const float ex = __builtin_fmaf(4e-6f, st0, X1 * p_ulp);
+      const float g_t = 2e-6f * (st0 + X1 * eps_o) * r_hi;  // rounding of the literal t
+      const float t_lo = (xbs - ex) * r_lo - 1.001f * eps_o - g_t;
+      const float t_hi = (xbs + ex) * r_hi + g_t;
+      const bool inside = !open && (ybs - su > 0.0f) && (zbs - sv > 0.0f) && ((ybs + zbs) + (su + sv) < dlo * 0.99999f) &&
+                          (xbs > ex) && (t_lo > 2e-7f) && (t_hi < (len - delta) - 1.01f * eps_o - 3e-7f * lenp) &&
+                          (dlo * rcp_lenp > __builtin_fmaf(2e-6f, X1, 2e-7f));
+      L.umbra |= __ballot(lanes && inside);
+    }
+    return false;
   };
   const unsigned long long grp = __ballot(alive);
   if (!grp) return L;
@@ -699,6 +720,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
           L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
           L.count++;
         }
+        if ((L.umbra & grp) == grp) return L;  // every lane is in full shadow: nothing left to find
       } else if (second) {
         in1 = true;
       } else {
@@ -1114,6 +1136,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     cand.reg = 0;
     cand.count = RT_CAND_OVERFLOW;
     cand.spheres = 0xFFFFFFFFu;
+    cand.umbra = 0ull;
     if ((RT_SKIP & 4) && N > 1) {  // removal ablation: no candidate collection either
       cand.count = 0;
       cand.spheres = 0;
@@ -1142,6 +1165,14 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         W.prof[6] += nsph;
       }
 #endif
+    }
+    if (cand.umbra) {
+      // lanes in the full shadow of an opaque triangle are done with this light
+      use = use && !((cand.umbra >> (threadIdx.x & 63u)) & 1ull);
+      if (!__ballot(use)) {
+        wv.cnt_shadow += N * (uint32_t)__popcll(__ballot(hit));
+        continue;
+      }
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
 #if RT_PROFILE == 3
