@@ -69,7 +69,7 @@ struct rt_scene {
   int device = 0;
   RtDevScene dev{};
   rt_bvh_info info{};
-  DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes;
+  DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes, nodes_oct;
   // per-render workspaces
   DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
   std::vector<uint32_t> sup_host;
@@ -96,7 +96,7 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
-                    &s->lights, &s->nodes, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
+                    &s->lights, &s->nodes, &s->nodes_oct, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -202,6 +202,39 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       if (no_split[ids[slot] & ~RT_TRI_DUPLICATE]) ids[slot] |= RT_TRI_TRANSMISSIVE;
     if ((rc = upload(s->tri_id, ids.data(), (size_t)n_slots * 4)) != RT_OK) return bail(rc);
     if ((rc = upload(s->nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
+    {
+      // per-octant copies for the soft-shadow candidate walk: planes pre-selected (lo = entry, hi = exit), the
+      // child that is entered first along the octant's diagonal stored first
+      const size_t nn = bvh.nodes.size();
+      std::vector<RtNode> oct(8 * nn);
+      for (uint32_t o = 0; o < 8; o++)
+        for (size_t i = 0; i < nn; i++) {
+          const RtNode& src = bvh.nodes[i];
+          RtNode d0 = src;
+          float key[2] = {0.f, 0.f};
+          for (int a = 0; a < 3; a++) {
+            const bool neg = (o >> a) & 1u;
+            if (src.c0 != RT_NODE_EMPTY) {
+              d0.lo0[a] = neg ? src.hi0[a] : src.lo0[a];
+              d0.hi0[a] = neg ? src.lo0[a] : src.hi0[a];
+              key[0] += neg ? -src.hi0[a] : src.lo0[a];
+            }
+            if (src.c1 != RT_NODE_EMPTY) {
+              d0.lo1[a] = neg ? src.hi1[a] : src.lo1[a];
+              d0.hi1[a] = neg ? src.lo1[a] : src.hi1[a];
+              key[1] += neg ? -src.hi1[a] : src.lo1[a];
+            }
+          }
+          if (src.c0 != RT_NODE_EMPTY && src.c1 != RT_NODE_EMPTY && key[1] < key[0]) {
+            RtNode sw = d0;
+            memcpy(sw.lo0, d0.lo1, 12), memcpy(sw.hi0, d0.hi1, 12), sw.c0 = d0.c1, sw.n0 = d0.n1;
+            memcpy(sw.lo1, d0.lo0, 12), memcpy(sw.hi1, d0.hi0, 12), sw.c1 = d0.c0, sw.n1 = d0.n0;
+            d0 = sw;
+          }
+          oct[o * nn + i] = d0;
+        }
+      if ((rc = upload(s->nodes_oct, oct.data(), oct.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
+    }
   }
   {
     std::vector<float> m(12 * (size_t)d->n_materials, 0.f);
@@ -231,6 +264,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
   s->dev.tri_id = (const uint32_t*)s->tri_id.p;
   s->dev.materials = (const float4*)s->materials.p;
   s->dev.lights = (const float4*)s->lights.p;
+  s->dev.nodes_oct = (const RtNode*)s->nodes_oct.p;
   s->dev.nodes = (const RtNode*)s->nodes.p;
   s->dev.n_spheres = ns;
   s->dev.n_triangles = nt;

@@ -61,6 +61,9 @@ struct RtDevScene {
   const float4* materials;
   const float4* lights;
   const RtNode* nodes;
+  // 8 copies of nodes, one per direction octant o (bit a = direction negative along axis a): lo* hold the entry
+  // planes and hi* the exit planes for that octant, children are in near-first order (octant o: [o * n_nodes ...])
+  const RtNode* nodes_oct;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
   uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
 };

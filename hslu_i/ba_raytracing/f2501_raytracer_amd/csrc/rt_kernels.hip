@@ -553,18 +553,12 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
   // The 64 segments of a wavefront (a few neighbouring pixels, one light) nearly always point into the same
-  // octant.  Then the entry / exit plane of every axis is the same for all lanes and is picked with scalar
-  // selects on the node's SGPR copy; the inflation folds into the per-lane fma constants: 6 fma + max3 + min3
-  // per box instead of 12 fma + 6 min/max + 4 min/max.
-  // (mask-and-xor on the bit patterns instead of ?: -- hipcc turns a uniform float select into v_mov + v_cndmask)
-  auto box_uniform = [&](const float* lo, const float* hi, uint32_t mx, uint32_t my, uint32_t mz, float& smin) {
-    const uint32_t lx = __float_as_uint(lo[0]), hx = __float_as_uint(hi[0]), tx = (lx ^ hx) & mx;
-    const uint32_t ly = __float_as_uint(lo[1]), hy = __float_as_uint(hi[1]), ty = (ly ^ hy) & my;
-    const uint32_t lz = __float_as_uint(lo[2]), hz = __float_as_uint(hi[2]), tz = (lz ^ hz) & mz;
-    smin = fmaxf(fmaxf(__builtin_fmaf(__uint_as_float(lx ^ tx), inv.x, cn.x), __builtin_fmaf(__uint_as_float(ly ^ ty), inv.y, cn.y)),
-                 __builtin_fmaf(__uint_as_float(lz ^ tz), inv.z, cn.z));
-    float smax = fminf(fminf(__builtin_fmaf(__uint_as_float(hx ^ tx), inv.x, cf.x), __builtin_fmaf(__uint_as_float(hy ^ ty), inv.y, cf.y)),
-                       __builtin_fmaf(__uint_as_float(hz ^ tz), inv.z, cf.z));
+  // octant.  Then the entry / exit plane of every axis is the same for all lanes -- the octant's copy of the
+  // tree (RtDevScene::nodes_oct) holds them pre-selected -- and the inflation folds into the per-lane fma
+  // constants: 6 fma + max3 + min3 per box instead of 12 fma + 6 min/max + 4 min/max.
+  auto box_planes = [&](const float* near, const float* far, float& smin) {  // planes already selected for the octant
+    smin = fmaxf(fmaxf(__builtin_fmaf(near[0], inv.x, cn.x), __builtin_fmaf(near[1], inv.y, cn.y)), __builtin_fmaf(near[2], inv.z, cn.z));
+    float smax = fminf(fminf(__builtin_fmaf(far[0], inv.x, cf.x), __builtin_fmaf(far[1], inv.y, cf.y)), __builtin_fmaf(far[2], inv.z, cf.z));
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
     return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
   };
@@ -680,69 +674,85 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   const unsigned long long mx = __ballot(__float_as_uint(inv.x) >> 31) & grp, my = __ballot(__float_as_uint(inv.y) >> 31) & grp,
                            mz = __ballot(__float_as_uint(inv.z) >> 31) & grp;
   const bool octant_uniform = (mx == 0 || mx == grp) && (my == 0 || my == grp) && (mz == 0 || mz == grp);
-  // all-ones where the octant is negative along the axis (kept in SGPRs)
-  const uint32_t neg_x = __builtin_amdgcn_readfirstlane(mx != 0 ? 0xFFFFFFFFu : 0u), neg_y = __builtin_amdgcn_readfirstlane(my != 0 ? 0xFFFFFFFFu : 0u),
-                 neg_z = __builtin_amdgcn_readfirstlane(mz != 0 ? 0xFFFFFFFFu : 0u);
-  uint32_t stk = 0, sp = 0, node = 0;
-  for (;;) {
-    const RtNode nd = uload(&sc.nodes[node]);
-    W.s_nodes++;
-    float tn0, tn1;
-    bool h0, h1;
-    if (octant_uniform) {
-      h0 = box_uniform(nd.lo0, nd.hi0, neg_x, neg_y, neg_z, tn0);
-      h1 = box_uniform(nd.lo1, nd.hi1, neg_x, neg_y, neg_z, tn1);
-    } else {
-      h0 = box(nd.lo0, nd.hi0, tn0);
-      h1 = box(nd.lo1, nd.hi1, tn1);
+  // One walk, two instantiations.  Uniform octant (the rule): the octant's copy of the tree already holds the
+  // entry / exit planes in lo / hi and its children in near-first order, so a node costs 12 fma + 2 max3/min3 and
+  // no ordering vote.  Mixed octants: the generic slab test and a vote, on the original nodes.
+  auto walk = [&](auto uni_tag) {
+    constexpr bool UNI = decltype(uni_tag)::value;
+    const RtNode* nodes = sc.nodes;
+    if (UNI) {
+      const uint32_t oct = (mx ? 1u : 0u) | (my ? 2u : 0u) | (mz ? 4u : 0u);
+      nodes = sc.nodes_oct + (size_t)__builtin_amdgcn_readfirstlane(oct) * sc.n_nodes;
     }
-    const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & grp) : 0ull;
-    const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & grp) : 0ull;
-    // near-first order so that early occluders are tested first by every sample
-    const unsigned long long both = b0 & b1;
-    const bool first1 = both && (2 * __popcll(__ballot(tn1 < tn0) & both) > __popcll(both));
-    uint32_t next = RT_NODE_EMPTY;
-    bool in0 = false, in1 = false;
-    // leaves are appended in visiting order (nearer child first)
-    for (int pass = 0; pass < 2; pass++) {
-      const bool second = (pass == 1) != first1;  // which child this pass handles
-      const unsigned long long b = second ? b1 : b0;
-      const uint32_t cc = second ? nd.c1 : nd.c0, nn = second ? nd.n1 : nd.n0;
-      if (!b) continue;
-      if (nn) {
-        if (L.count + nn > cand_cap) {
-          L.count = RT_CAND_OVERFLOW;
-          return L;
-        }
-        const bool in_leaf = (b >> lane_id) & 1ull;
-        for (uint32_t k = 0; k < nn; k++) {
-          if (beam_rejects_all(cc + k, in_leaf)) continue;  // no sample of any lane can hit it
-          L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
-          L.count++;
-        }
-        if ((L.umbra & grp) == grp) return L;  // every lane is in full shadow: nothing left to find
-      } else if (second) {
-        in1 = true;
+    uint32_t stk = 0, sp = 0, node = 0;
+    for (;;) {
+      const RtNode nd = uload(&nodes[node]);
+      W.s_nodes++;
+      float tn0, tn1;
+      bool h0, h1;
+      if (UNI) {
+        h0 = box_planes(nd.lo0, nd.hi0, tn0);
+        h1 = box_planes(nd.lo1, nd.hi1, tn1);
       } else {
-        in0 = true;
+        h0 = box(nd.lo0, nd.hi0, tn0);
+        h1 = box(nd.lo1, nd.hi1, tn1);
       }
+      // (an absent child has an inverted box in every copy: never hit)
+      const unsigned long long b0 = __ballot(h0) & grp;
+      const unsigned long long b1 = __ballot(h1) & grp;
+      // near-first order so that early occluders are tested first by every sample
+      bool first1 = false;
+      if (!UNI) {
+        const unsigned long long both = b0 & b1;
+        first1 = both && (2 * __popcll(__ballot(tn1 < tn0) & both) > __popcll(both));
+      }
+      uint32_t next = RT_NODE_EMPTY;
+      bool in0 = false, in1 = false;
+      // leaves are appended in visiting order (nearer child first)
+      for (int pass = 0; pass < 2; pass++) {
+        const bool second = (pass == 1) != first1;  // which child this pass handles
+        const unsigned long long b = second ? b1 : b0;
+        const uint32_t cc = second ? nd.c1 : nd.c0, nn = second ? nd.n1 : nd.n0;
+        if (!b) continue;
+        if (nn) {
+          if (L.count + nn > cand_cap) {
+            L.count = RT_CAND_OVERFLOW;
+            return;
+          }
+          const bool in_leaf = (b >> lane_id) & 1ull;
+          for (uint32_t k = 0; k < nn; k++) {
+            if (beam_rejects_all(cc + k, in_leaf)) continue;  // no sample of any lane can hit it
+            L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
+            L.count++;
+          }
+          if ((L.umbra & grp) == grp) return;  // every lane is in full shadow: nothing left to find
+        } else if (second) {
+          in1 = true;
+        } else {
+          in0 = true;
+        }
+      }
+      if (in0 && in1) {
+        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
+        sp++;
+        next = first1 ? nd.c1 : nd.c0;
+      } else if (in0) {
+        next = nd.c0;
+      } else if (in1) {
+        next = nd.c1;
+      }
+      if (next == RT_NODE_EMPTY) {
+        if (sp == 0) break;
+        sp--;
+        next = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
+      }
+      node = next;
     }
-    if (in0 && in1) {
-      stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
-      sp++;
-      next = first1 ? nd.c1 : nd.c0;
-    } else if (in0) {
-      next = nd.c0;
-    } else if (in1) {
-      next = nd.c1;
-    }
-    if (next == RT_NODE_EMPTY) {
-      if (sp == 0) break;
-      sp--;
-      next = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
-    }
-    node = next;
-  }
+  };
+  if (octant_uniform)
+    walk(std::true_type{});
+  else
+    walk(std::false_type{});
   return L;
 }
 
@@ -790,6 +800,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
 #endif
   PROF_ADD(W, 3, t_sph);
   const unsigned long long t_tri = PROF_T();
+  (void)t_tri;
 
   auto test_tri_q = [&](uint32_t slot, float4 q0, float4 q1, float4 q2, bool lane_on) {
     float t;
