@@ -51,6 +51,14 @@
 #define RT_DOUBLE 0
 #endif
 #define RT_OPAQUE(v) asm volatile("" : "+v"(v))
+// Lane mask of a predicate.  HIP's __ballot(int) first widens the bool to an int in a VGPR and compares it back
+// (v_cndmask + v_cmp per vote); the builtin takes the i1 as it is (the compare result already is the mask).
+#define wave_ballot(pred) __builtin_amdgcn_ballot_w64((bool)(pred))
+// hipcc only folds a vote into its compare when the predicate IS one compare; a combined predicate costs a
+// v_cndmask + v_cmp round trip.  So lane sets are kept as 64-bit masks (SGPR pairs) and combined with scalar
+// and/or/andn2; lane_of() turns a mask back into a per-lane predicate where a select needs one (free).
+typedef unsigned long long lanemask;
+#define lane_of(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 // Diagnostic build (make PROFILE=1 -> librt_hip_prof.so): wave-level shader-clock timers (s_memtime) around
 // the regions of the light loop; their sums replace the work counters in rt_stats (tools/perf_ab.py --prof).
 #ifndef RT_PROFILE
@@ -104,7 +112,7 @@ __device__ __forceinline__ V3 reflected(V3 v, V3 n) {
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
   return fminf(fmaxf(x, lo), hi);
 }
-__device__ __forceinline__ bool has_nan(V3 a) { return (a.x != a.x) | (a.y != a.y) | (a.z != a.z); }
+__device__ __forceinline__ bool has_nan(V3 a) { return (a.x != a.x) || (a.y != a.y) || (a.z != a.z); }
 
 // Wave-uniform load: the address is the same in every lane, so read it through the constant address
 // space -> s_load_dwordx4/x8/x16 into SGPRs (scalar cache -> L2) instead of 64 identical vector loads.
@@ -257,8 +265,8 @@ __device__ __forceinline__ bool sphere_hit(float4 s, V3 o, V3 d, float& t_out) {
 //   phase 2  the literal sequence (same op order as the oracle), only if some lane survived.
 // y, z, b and det_i are shared by both phases and computed exactly as the literal code does.
 #define RT_TRI_G 2e-6f
-__device__ __forceinline__ bool tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, bool lane_on, float tlimit,
-                                        float& t_out, uint32_t& n_exact) {
+__device__ __forceinline__ lanemask tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, lanemask on, float tlimit,
+                                            float& t_out, uint32_t& n_exact) {
   V3 v1 = mk(q0.x, q0.y, q0.z);
   V3 c1 = mk(-q0.w, -q1.x, -q1.y);  // -e1
   V3 c2 = mk(-q1.z, -q1.w, -q2.x);  // -e2
@@ -275,23 +283,23 @@ __device__ __forceinline__ bool tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V
     float yb = __builtin_fmaf(y.x, b.x, __builtin_fmaf(y.y, b.y, y.z * b.z));
     float su = __builtin_fmaf(fabsf(y.x), ab.x, __builtin_fmaf(fabsf(y.y), ab.y, fabsf(y.z) * ab.z));
     float ybs = __uint_as_float(__float_as_uint(yb) ^ sgn);  // (y.b) * sign(det)
-    lane_on = lane_on && !(ybs < -RT_TRI_G * su);  // NaN anywhere -> comparison false -> not rejected
-    if (!__ballot(lane_on)) return false;
+    on &= ~wave_ballot(ybs < -RT_TRI_G * su);  // NaN anywhere -> comparison false -> not rejected
+    if (!on) return 0ull;
     z = mk((d.y * c1.z) + (-d.z * c1.y), (d.z * c1.x) + (-d.x * c1.z), (d.x * c1.y) + (-d.y * c1.x));
     float zb = __builtin_fmaf(z.x, b.x, __builtin_fmaf(z.y, b.y, z.z * b.z));
     float sv = __builtin_fmaf(fabsf(z.x), ab.x, __builtin_fmaf(fabsf(z.y), ab.y, fabsf(z.z) * ab.z));
     float zbs = __uint_as_float(__float_as_uint(zb) ^ sgn);
     float ad = fabsf(det_i);
-    lane_on = lane_on && !((zbs < -RT_TRI_G * sv) || ((ybs + zbs) - ad > RT_TRI_G * ((su + sv) + ad)));
-    if (!__ballot(lane_on)) return false;
+    on &= ~(wave_ballot(zbs < -RT_TRI_G * sv) | wave_ballot((ybs + zbs) - ad > RT_TRI_G * ((su + sv) + ad)));
+    if (!on) return 0ull;
     // t ~ (x.b)/det: certainly <= 0 (the literal needs t > eps), or certainly beyond the caller's limit
     // (nearest hit: current best t; shadow ray: distance to the light) -- such a hit cannot count
     float xb = __builtin_fmaf(x.x, b.x, __builtin_fmaf(x.y, b.y, x.z * b.z));
     float st = __builtin_fmaf(fabsf(x.x), ab.x, __builtin_fmaf(fabsf(x.y), ab.y, fabsf(x.z) * ab.z));
     float xbs = __uint_as_float(__float_as_uint(xb) ^ sgn);
     float tl_ad = tlimit * ad;  // inf * 0 = NaN -> comparison false -> no rejection
-    lane_on = lane_on && !((xbs < -RT_TRI_G * st) || (xbs - tl_ad > RT_TRI_G * (st + tl_ad)));
-    if (!__ballot(lane_on)) return false;
+    on &= ~(wave_ballot(xbs < -RT_TRI_G * st) | wave_ballot(xbs - tl_ad > RT_TRI_G * (st + tl_ad)));
+    if (!on) return 0ull;
   }
   n_exact++;
   // ---- phase 2: literal -----------------------------------------------------------------------------
@@ -302,11 +310,11 @@ __device__ __forceinline__ bool tri_hit(float4 q0, float4 q1, float4 q2, V3 o, V
   float v = r2.x * b.x + r2.y * b.y + r2.z * b.z;
   // determinant(): first cofactor c1.y*c2.z - c2.y*c1.z is bit-equal to X.x (same two products)
   float det = d.x * x.x - c1.x * (d.y * c2.z - c2.y * d.z) + c2.x * (d.y * c1.z - c1.y * d.z);
-  bool t_invalid = t <= RT_EPS;
-  bool uv_invalid = (u < 0.0f) || (v < 0.0f) || ((u + v) >= 1.0f);
-  bool valid = !(t_invalid || uv_invalid) && !(fabsf(det - 0.0f) <= RT_EPS);
+  const lanemask t_invalid = wave_ballot(t <= RT_EPS);
+  const lanemask uv_invalid = wave_ballot(u < 0.0f) | wave_ballot(v < 0.0f) | wave_ballot((u + v) >= 1.0f);
+  const lanemask det_invalid = wave_ballot(fabsf(det - 0.0f) <= RT_EPS);
   t_out = t;
-  return lane_on && valid;
+  return on & ~(t_invalid | uv_invalid | det_invalid);
 }
 
 // per-ray constants of the slab test: reciprocal direction (magnitude clamped so that no inf and
@@ -335,15 +343,15 @@ __device__ __forceinline__ void box_one(const float* lo, const float* hi, const 
   tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
   tmax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
 }
-__device__ __forceinline__ void box_pair(const RtNode& nd, const BoxRay& r, float tlimit_s, bool& h0, bool& h1,
+__device__ __forceinline__ void box_pair(const RtNode& nd, const BoxRay& r, float tlimit_s, lanemask& h0, lanemask& h1,
                                          float& tn0, float& tn1) {
   float tm0, tm1;
   box_one(nd.lo0, nd.hi0, r, tn0, tm0);
   box_one(nd.lo1, nd.hi1, r, tn1, tm1);
   float s0 = __builtin_fmaf(fabsf(tm0), 4e-6f, tm0 + 1e-5f);
   float s1 = __builtin_fmaf(fabsf(tm1), 4e-6f, tm1 + 1e-5f);
-  h0 = (tn0 <= fminf(s0, tlimit_s)) & (s0 >= 0.0f);
-  h1 = (tn1 <= fminf(s1, tlimit_s)) & (s1 >= 0.0f);
+  h0 = wave_ballot(tn0 <= fminf(s0, tlimit_s)) & wave_ballot(s0 >= 0.0f);
+  h1 = wave_ballot(tn1 <= fminf(s1, tlimit_s)) & wave_ballot(s1 >= 0.0f);
 }
 __device__ __forceinline__ float t_limit_slack(float tlimit) {
   return __builtin_fmaf(fabsf(tlimit), 4e-6f, tlimit + 1e-5f);
@@ -354,21 +362,25 @@ struct Hit {
 };
 
 struct Shadow {
-  bool occluded;
+  lanemask occ;  // lanes that are completely occluded (wave-uniform mask)
   float opacity;
   V3 filter;
 };
 
-// one transmissive / opaque occluder on a shadow ray, raytracer.rs:53-92
-__device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n, V3 d) {
+// one transmissive / opaque occluder on a shadow ray, raytracer.rs:53-92, applied to the lanes in `h`
+// (predicated, outside divergent control flow, so that S.occ stays a wave-uniform mask; m is wave-uniform)
+__device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
   float io = 0.0f;
   if (m.transmissive) {
     V3 refl = fresnel_reflectance(m, n, -d, 1.0f);
     io = m.opacity * (1.0f - refl.x);
   }
-  S.opacity = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
-  if (!m.transmissive && fabsf(S.opacity - 0.0f) <= RT_EPS) S.occluded = true;
-  S.filter = S.filter - absorption(m);
+  const bool on = lane_of(h);
+  const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
+  S.opacity = on ? nop : S.opacity;
+  if (!m.transmissive) S.occ |= h & wave_ballot(fabsf(nop - 0.0f) <= RT_EPS);
+  const V3 nf = S.filter - absorption(m);
+  S.filter = mk(on ? nf.x : S.filter.x, on ? nf.y : S.filter.y, on ? nf.z : S.filter.z);
 }
 
 struct WaveCtx {
@@ -407,32 +419,33 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   if (sc.n_triangles == 0) return best;
   const int tri_base = (int)sc.n_spheres;
 
-  auto test_tri = [&](uint32_t slot, bool lane_on) {
+  auto test_tri = [&](uint32_t slot, lanemask lanes) {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
     float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
     float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
     float t;
-    bool h = tri_hit(q0, q1, q2, o, d, lane_on, best.t, t, W.n_exact);
+    lanemask h = tri_hit(q0, q1, q2, o, d, lanes, best.t, t, W.n_exact);
     if (CULL) {  // triangle.rs:154-168
-      if (__ballot(h)) {
+      if (h) {
         float4 sh = uload(&sc.tri_shade[slot]);
         Mat m = load_mat_u(sc, __float_as_uint(sh.w));
-        h = h && ((dot(d, mk(sh.x, sh.y, sh.z)) < 0.75f) || m.transmissive);
+        if (!m.transmissive) h &= wave_ballot(dot(d, mk(sh.x, sh.y, sh.z)) < 0.75f);
       }
     }
-    if (__ballot(h)) {
+    if (h) {
       int id = tri_base + (int)(uload(&sc.tri_id[slot]) & RT_TRI_INDEX_MASK);
-      if (h && (t < best.t || (t == best.t && id > best.id))) {
+      if (lane_of(h) && (t < best.t || (t == best.t && id > best.id))) {
         best.t = t;
         best.id = id;
       }
     }
   };
 
+  const lanemask grp = wave_ballot(alive);
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     // the literal scan visits every triangle once: skip the extra references of split triangles
     for (uint32_t s = 0; s < sc.n_slots; s++)
-      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, alive);
+      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return best;
   }
 
@@ -440,7 +453,6 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   const uint32_t lane_id = threadIdx.x & 63u;
   // The traversal stack is ONE stack per wavefront, held in the 64 lanes of a single VGPR
   // (push = select on lane id, pop = v_readlane with a scalar lane index): no LDS round trip.
-  const unsigned long long grp = __ballot(alive);
   {
     uint32_t stk = 0;
     uint32_t sp = 0;
@@ -449,17 +461,16 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       const RtNode nd = uload(&sc.nodes[node]);
       W.n_nodes++;
       float tn0, tn1;
-      bool h0, h1;
+      lanemask h0, h1;
       box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
-      const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & grp) : 0ull;
-      const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & grp) : 0ull;
+      const lanemask b0 = nd.c0 != RT_NODE_EMPTY ? (h0 & grp) : 0ull;
+      const lanemask b1 = nd.c1 != RT_NODE_EMPTY ? (h1 & grp) : 0ull;
       uint32_t next = RT_NODE_EMPTY;
       bool in0 = false, in1 = false;  // internal children to descend into
       if (b0) {
         if (nd.n0) {
           W.n_tris += nd.n0;
-          const bool on = (b0 >> lane_id) & 1ull;
-          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, on);
+          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, b0);
         } else {
           in0 = true;
         }
@@ -467,8 +478,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       if (b1) {
         if (nd.n1) {
           W.n_tris += nd.n1;
-          const bool on = (b1 >> lane_id) & 1ull;
-          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, on);
+          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, b1);
         } else {
           in1 = true;
         }
@@ -476,7 +486,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       if (in0 && in1) {
         // near-first by wave vote among lanes that hit both children
         const unsigned long long both = b0 & b1;
-        const unsigned long long pref1 = __ballot(tn1 < tn0) & both;
+        const unsigned long long pref1 = wave_ballot(tn1 < tn0) & both;
         const bool first1 = 2 * __popcll(pref1) > __popcll(both);
         stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;  // push: lane `sp` of the stack register
         sp++;
@@ -550,7 +560,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
                              fmaxf(__builtin_fmaf(lo[1], inv.y, cf.y), __builtin_fmaf(hi[1], inv.y, cf.y))),
                        fmaxf(__builtin_fmaf(lo[2], inv.z, cf.z), __builtin_fmaf(hi[2], inv.z, cf.z)));
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
-    return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
+    return wave_ballot(smin <= fminf(smax_s, send)) & wave_ballot(smax_s >= sbeg);
   };
   // The 64 segments of a wavefront (a few neighbouring pixels, one light) nearly always point into the same
   // octant.  Then the entry / exit plane of every axis is the same for all lanes -- the octant's copy of the
@@ -560,7 +570,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     smin = fmaxf(fmaxf(__builtin_fmaf(near[0], inv.x, cn.x), __builtin_fmaf(near[1], inv.y, cn.y)), __builtin_fmaf(near[2], inv.z, cn.z));
     float smax = fminf(fminf(__builtin_fmaf(far[0], inv.x, cf.x), __builtin_fmaf(far[1], inv.y, cf.y)), __builtin_fmaf(far[2], inv.z, cf.z));
     float smax_s = __builtin_fmaf(fabsf(smax), 8e-6f, smax + 1e-5f);
-    return (smin <= fminf(smax_s, send)) & (smax_s >= sbeg);
+    return wave_ballot(smin <= fminf(smax_s, send)) & wave_ballot(smax_s >= sbeg);
   };
   // Beam-level barycentric rejection.  Every sample ray j of this lane is (o_j, D_j) = (p + do, dseg + dd)
   // with |do| <= eps_o, |dd| <= delta (un-normalised direction; u and v do not depend on its length).
@@ -587,7 +597,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   const float eps_o = __builtin_fmaf(2.6e-7f, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)), P.beam_eps_o);  // 1.01 eps + 2 p_ulp >= |so_j - p|
   // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
   // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
-  auto beam_rejects_all = [&](uint32_t slot, bool lanes) -> bool {
+  auto beam_rejects_all = [&](uint32_t slot, lanemask lanes) -> bool {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
     float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
     float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
@@ -599,28 +609,27 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float geo = __builtin_fmaf(delta, B, lenp * eps_o) + 2e-6f * lenp * B;  // per unit edge length
     float ad = fabsf(det);
     float dslack = __builtin_fmaf(delta, X1, 2e-6f * lenp * X1);
-    bool open = lanes && !(ad > dslack * 1.001f);  // sign of det unknown inside the beam: cannot reject
+    const lanemask open = lanes & ~wave_ballot(ad > dslack * 1.001f);  // sign of det unknown inside the beam: cannot reject
     const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
     // t: the surface the hit point lies on, and everything behind it
     float xbs = __uint_as_float(__float_as_uint(dot(x, b)) ^ sgn);
     float st0 = __builtin_fmaf(fabsf(x.x), fabsf(b.x), __builtin_fmaf(fabsf(x.y), fabsf(b.y), fabsf(x.z) * fabsf(b.z)));
-    bool rej = __builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack);
-    if (!__ballot(lanes && (open || !rej))) return true;
+    lanemask rej = wave_ballot(__builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack));
+    if (!(lanes & (open | ~rej))) return true;
     // u
     V3 y = mk((c2.y * dseg.z) + (-c2.z * dseg.y), (c2.z * dseg.x) + (-c2.x * dseg.z), (c2.x * dseg.y) + (-c2.y * dseg.x));
     float E2 = fabsf(c2.x) + fabsf(c2.y) + fabsf(c2.z);
     float ybs = __uint_as_float(__float_as_uint(dot(y, b)) ^ sgn);
     float su = E2 * geo;
-    rej |= ybs + su < 0.0f;
-    if (!__ballot(lanes && (open || !rej))) return true;
+    rej |= wave_ballot(ybs + su < 0.0f);
+    if (!(lanes & (open | ~rej))) return true;
     // v, u + v
     V3 z = mk((dseg.y * c1.z) + (-dseg.z * c1.y), (dseg.z * c1.x) + (-dseg.x * c1.z), (dseg.x * c1.y) + (-dseg.y * c1.x));
     float E1 = fabsf(c1.x) + fabsf(c1.y) + fabsf(c1.z);
     float zbs = __uint_as_float(__float_as_uint(dot(z, b)) ^ sgn);
     float sv = E1 * geo;
-    rej |= (zbs + sv < 0.0f) | ((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
-    const unsigned long long keep = __ballot(lanes && (open || !rej));
-    if (!keep) return true;
+    rej |= wave_ballot(zbs + sv < 0.0f) | wave_ballot((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
+    if (!(lanes & (open | ~rej))) return true;
     // Umbra: the triangle is opaque and EVERY sample ray of the lane hits it between origin and light -- the
     // literal test would accept it for each j (u_j, v_j >= 0, u_j + v_j < 1, EPS < t_j <= tmax_j, |det_j| > EPS,
     // all by margins that cover the rounding of the literal sequence), so the lane is occluded for this light
@@ -633,14 +642,15 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       const float g_t = 2e-6f * (st0 + X1 * eps_o) * r_hi;  // rounding of the literal t
       const float t_lo = (xbs - ex) * r_lo - 1.001f * eps_o - g_t;
       const float t_hi = (xbs + ex) * r_hi + g_t;
-      const bool inside = !open && (ybs - su > 0.0f) && (zbs - sv > 0.0f) && ((ybs + zbs) + (su + sv) < dlo * 0.99999f) &&
-                          (xbs > ex) && (t_lo > 2e-7f) && (t_hi < (len - delta) - 1.01f * eps_o - 3e-7f * lenp) &&
-                          (dlo * rcp_lenp > __builtin_fmaf(2e-6f, X1, 2e-7f));
-      L.umbra |= __ballot(lanes && inside);
+      const lanemask inside = wave_ballot(ybs - su > 0.0f) & wave_ballot(zbs - sv > 0.0f) &
+                              wave_ballot((ybs + zbs) + (su + sv) < dlo * 0.99999f) & wave_ballot(xbs > ex) & wave_ballot(t_lo > 2e-7f) &
+                              wave_ballot(t_hi < (len - delta) - 1.01f * eps_o - 3e-7f * lenp) &
+                              wave_ballot(dlo * rcp_lenp > __builtin_fmaf(2e-6f, X1, 2e-7f));
+      L.umbra |= lanes & ~open & inside;
     }
     return false;
   };
-  const unsigned long long grp = __ballot(alive);
+  const unsigned long long grp = wave_ballot(alive);
   if (!grp) return L;
   // spheres: every point of every sample ray lies within delta of the centre segment, so a sphere
   // whose centre is farther than r + delta from that segment cannot be touched by any of them
@@ -661,18 +671,18 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       // is positive by more than the rounding of disc = b^2 - 4 cc (b^2 <= 4 |v|^2) and d_j.v_j > 0.  Over the beam
       // d_j.v0 >= (-w.dseg - delta |w|) / Lp =: amin and cc_j >= cc0 + 2 eps_d amin - rounding.  This is the sphere
       // the hit point lies on (lit side) and every sphere behind the hit point.
-      if (!__ballot(alive && near)) continue;
+      if (!wave_ballot(alive && near)) continue;
       const float wl2 = dot(w, w), w1 = fabsf(w.x) + fabsf(w.y) + fabsf(w.z);
       const float amin = (-wd - delta * w1) * rcp_lenp;
       const float cc_lo = (wl2 - sp4.w) + P.beam_eps_198 * amin - (6e-6f * wl2 + 4.0f * p_ulp * w1);
       const bool leaving = (amin > 1e-6f * w1) && (cc_lo > 0.0f);
-      if (__ballot(alive && near && !leaving)) mask |= 1u << i;
+      if (wave_ballot(alive && near && !leaving)) mask |= 1u << i;
     }
     L.spheres = mask | (sc.n_spheres > 32u ? 0xFFFFFFFFu : 0u);
   }
   // direction octant of the wavefront (sign of inv = sign of dseg, -0 included)
-  const unsigned long long mx = __ballot(__float_as_uint(inv.x) >> 31) & grp, my = __ballot(__float_as_uint(inv.y) >> 31) & grp,
-                           mz = __ballot(__float_as_uint(inv.z) >> 31) & grp;
+  const unsigned long long mx = wave_ballot(__float_as_uint(inv.x) >> 31) & grp, my = wave_ballot(__float_as_uint(inv.y) >> 31) & grp,
+                           mz = wave_ballot(__float_as_uint(inv.z) >> 31) & grp;
   const bool octant_uniform = (mx == 0 || mx == grp) && (my == 0 || my == grp) && (mz == 0 || mz == grp);
   // One walk, two instantiations.  Uniform octant (the rule): the octant's copy of the tree already holds the
   // entry / exit planes in lo / hi and its children in near-first order, so a node costs 12 fma + 2 max3/min3 and
@@ -689,7 +699,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       const RtNode nd = uload(&nodes[node]);
       W.s_nodes++;
       float tn0, tn1;
-      bool h0, h1;
+      lanemask h0, h1;
       if (UNI) {
         h0 = box_planes(nd.lo0, nd.hi0, tn0);
         h1 = box_planes(nd.lo1, nd.hi1, tn1);
@@ -698,13 +708,13 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
         h1 = box(nd.lo1, nd.hi1, tn1);
       }
       // (an absent child has an inverted box in every copy: never hit)
-      const unsigned long long b0 = __ballot(h0) & grp;
-      const unsigned long long b1 = __ballot(h1) & grp;
+      const lanemask b0 = h0 & grp;
+      const lanemask b1 = h1 & grp;
       // near-first order so that early occluders are tested first by every sample
       bool first1 = false;
       if (!UNI) {
         const unsigned long long both = b0 & b1;
-        first1 = both && (2 * __popcll(__ballot(tn1 < tn0) & both) > __popcll(both));
+        first1 = both && (2 * __popcll(wave_ballot(tn1 < tn0) & both) > __popcll(both));
       }
       uint32_t next = RT_NODE_EMPTY;
       bool in0 = false, in1 = false;
@@ -719,9 +729,8 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
             L.count = RT_CAND_OVERFLOW;
             return;
           }
-          const bool in_leaf = (b >> lane_id) & 1ull;
           for (uint32_t k = 0; k < nn; k++) {
-            if (beam_rejects_all(cc + k, in_leaf)) continue;  // no sample of any lane can hit it
+            if (beam_rejects_all(cc + k, b)) continue;  // no sample of any lane can hit it
             L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
             L.count++;
           }
@@ -758,9 +767,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
 
 template <bool CULL>
 __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
-                                             bool alive, V3 o, V3 d_raw, float tmax, const CandList& cand) {
+                                             lanemask grp, V3 o, V3 d_raw, float tmax, const CandList& cand) {
   Shadow S;
-  S.occluded = false;
+  S.occ = 0ull;
   S.opacity = 1.0f;
   S.filter = mk(1.0f, 1.0f, 1.0f);
   V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
@@ -772,26 +781,16 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
     if (i < 32u && !((cand.spheres >> i) & 1u)) continue;  // culled for this (wavefront, light)
     float4 s = uload(&sc.spheres[i]);
-    float t;
-    bool h = alive && !S.occluded && sphere_hit(s, o, d, t);
-    if (RT_DOUBLE & 1) {
-      V3 o2 = o;
-      RT_OPAQUE(o2.x);
-      float t2;
-      bool h2 = alive && !S.occluded && sphere_hit(s, o2, d, t2);
-      h = h && (h2 || !h2);
-      if (h2) t = fminf(t, t2);
-    }
-    h = h && (t <= tmax);
-    if (__ballot(h)) {
-      if (h) {
-        V3 p = fma_s(d, t, o);
-        V3 n = normalize(p - mk(s.x, s.y, s.z));
-        Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
-        bool vis = true;
-        if (CULL) vis = (dot(d, n) < 0.75f) || m.transmissive;
-        if (vis) shadow_accumulate(S, m, n, d);
-      }
+    float t = 0.0f;
+    lanemask h = grp & ~S.occ & wave_ballot(sphere_hit(s, o, d, t));
+    h &= wave_ballot(t <= tmax);
+    if (h) {
+      // (computed for every lane, applied to the lanes in h: keeps S.occ a wave-uniform mask)
+      V3 p = fma_s(d, t, o);
+      V3 n = normalize(p - mk(s.x, s.y, s.z));
+      Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
+      if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
+      shadow_accumulate(S, m, n, d, h);
     }
   }
   if (sc.n_triangles == 0) return S;
@@ -799,50 +798,37 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   RT_OPAQUE(S.opacity);
 #endif
   PROF_ADD(W, 3, t_sph);
-  const unsigned long long t_tri = PROF_T();
-  (void)t_tri;
 
-  auto test_tri_q = [&](uint32_t slot, float4 q0, float4 q1, float4 q2, bool lane_on) {
-    float t;
-    bool h = tri_hit(q0, q1, q2, o, d, lane_on && !S.occluded, tmax, t, W.s_exact);
-    if (RT_DOUBLE & 2) {
-      V3 o2 = o;
-      RT_OPAQUE(o2.x);
-      float t2 = 0.0f;
-      bool h2 = tri_hit(q0, q1, q2, o2, d, lane_on && !S.occluded, tmax, t2, W.s_exact);
-      if (h2 && h) t = fminf(t, t2);
-    }
-    h = h && (t <= tmax);
-    if (__ballot(h)) {
-      float4 sh = uload(&sc.tri_shade[slot]);
-      Mat m = load_mat_u(sc, __float_as_uint(sh.w));
-      V3 n = mk(sh.x, sh.y, sh.z);
-      if (CULL) h = h && ((dot(d, n) < 0.75f) || m.transmissive);
-      if (h) shadow_accumulate(S, m, n, d);
-    }
-  };
-  auto test_tri = [&](uint32_t slot, bool lane_on) {
+  auto test_tri = [&](uint32_t slot, lanemask lanes) {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
     float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
     float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
-    test_tri_q(slot, q0, q1, q2, lane_on);
+    float t;
+    lanemask h = tri_hit(q0, q1, q2, o, d, lanes & ~S.occ, tmax, t, W.s_exact);
+    h &= wave_ballot(t <= tmax);
+    if (h) {
+      float4 sh = uload(&sc.tri_shade[slot]);
+      Mat m = load_mat_u(sc, __float_as_uint(sh.w));
+      V3 n = mk(sh.x, sh.y, sh.z);
+      if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
+      shadow_accumulate(S, m, n, d, h);
+    }
   };
 
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     for (uint32_t s = 0; s < sc.n_slots; s++)
-      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, alive);
+      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return S;
   }
   W.s_passes++;
-  const unsigned long long grp = __ballot(alive);
 
   if (cand.count != RT_CAND_OVERFLOW) {
     // soft shadows: test the triangle slots collected once for this (wavefront, light)
     W.s_tris += cand.count;
     for (uint32_t c = 0; c < cand.count; c++) {
-      if (!(grp & ~__ballot(S.occluded))) break;
+      if (!(grp & ~S.occ)) break;
       uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)cand.reg, (int)c);
-      test_tri(slot, alive);
+      test_tri(slot, grp);
     }
     return S;
   }
@@ -855,30 +841,21 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     uint32_t sp = 0;
     uint32_t node = 0;
     for (;;) {
-      const unsigned long long live = grp & ~__ballot(S.occluded);
+      const lanemask live = grp & ~S.occ;
       if (!live) break;
       const RtNode nd = uload(&sc.nodes[node]);
       W.s_nodes++;
       float tn0, tn1;
-      bool h0, h1;
+      lanemask h0, h1;
       box_pair(nd, br, tl, h0, h1, tn0, tn1);
-      if (RT_DOUBLE & 4) {
-        BoxRay br2 = br;
-        RT_OPAQUE(br2.inv.x);
-        float a0, a1;
-        bool g0, g1;
-        box_pair(nd, br2, tl, g0, g1, a0, a1);
-        if (g0 != g1 && a0 + a1 == 123.456f) h0 = !h0;
-      }
-      const unsigned long long b0 = nd.c0 != RT_NODE_EMPTY ? (__ballot(h0) & live) : 0ull;
-      const unsigned long long b1 = nd.c1 != RT_NODE_EMPTY ? (__ballot(h1) & live) : 0ull;
+      const lanemask b0 = nd.c0 != RT_NODE_EMPTY ? (h0 & live) : 0ull;
+      const lanemask b1 = nd.c1 != RT_NODE_EMPTY ? (h1 & live) : 0ull;
       uint32_t next = RT_NODE_EMPTY;
       bool in0 = false, in1 = false;
       if (b0) {
         if (nd.n0) {
           W.s_tris += nd.n0;
-          const bool on = (b0 >> lane_id) & 1ull;
-          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, on);
+          for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, b0);
         } else {
           in0 = true;
         }
@@ -886,8 +863,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (b1) {
         if (nd.n1) {
           W.s_tris += nd.n1;
-          const bool on = (b1 >> lane_id) & 1ull;
-          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, on);
+          for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, b1);
         } else {
           in1 = true;
         }
@@ -896,7 +872,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
         // any-hit: visit the child that is nearer for most lanes first -- an early occluder ends the
         // traversal for the whole wavefront
         const unsigned long long both = b0 & b1;
-        const unsigned long long pref1 = __ballot(tn1 < tn0) & both;
+        const unsigned long long pref1 = wave_ballot(tn1 < tn0) & both;
         const bool first1 = 2 * __popcll(pref1) > __popcll(both);
         stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
         sp++;
@@ -1015,7 +991,7 @@ struct RayOut {
 // appends the lanes with `on` to the ray queue (wave-level compaction: one atomic per wavefront)
 __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, V3 d, float n_start, V3 Wt,
                                            int depth, int kind, uint32_t pix) {
-  unsigned long long m = __ballot(on);
+  unsigned long long m = wave_ballot(on);
   if (!m) return;
   uint32_t n = (uint32_t)__popcll(m);
   uint32_t base = 0;
@@ -1056,14 +1032,14 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   const unsigned long long t_all = PROF_T();
   V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
   bool alive = have && !has_nan(d);
-  unsigned long long bal = __ballot(alive);
+  unsigned long long bal = wave_ballot(alive);
   if (!bal) return out;
   Hit h = pre;
   if (!PRE) {
     // ray accounting: lanes entering cast_ray, by kind
-    wv.cnt_kind[0] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_PRIMARY));
-    wv.cnt_kind[1] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_kind[0] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_PRIMARY));
+    wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
     wv.cnt_pass += 1;
     wv.cnt_lanes += (uint32_t)__popcll(bal);
     const unsigned long long t_n = PROF_T();
@@ -1077,7 +1053,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   out.hit = hit;
   out.t = h.t;
   out.id = hit ? h.id : -1;
-  if (!__ballot(hit)) return out;
+  const lanemask hit_m = wave_ballot(hit);
+  if (!hit_m) return out;
 
   {
     // Park what the light loop does not need in LDS (SoA, one dword per lane per field: conflict
@@ -1139,8 +1116,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       const float scale = fabsf(dc.x) + fabsf(dc.y) + fabsf(dc.z) + fabsf(sf.p.x) + fabsf(sf.p.y) + fabsf(sf.p.z) + 1.0f;
       use = hit && (dot(sf.n, dc) + n1 * __builtin_fmaf(4e-6f, scale, dl) > 0.0f);
     }
-    if (!__ballot(use)) {
-      wv.cnt_shadow += N * (uint32_t)__popcll(__ballot(hit));
+    lanemask use_m = wave_ballot(use);
+    if (!use_m) {
+      wv.cnt_shadow += N * (uint32_t)__popcll(hit_m);
       continue;
     }
     CandList cand;
@@ -1179,9 +1157,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     }
     if (cand.umbra) {
       // lanes in the full shadow of an opaque triangle are done with this light
-      use = use && !((cand.umbra >> (threadIdx.x & 63u)) & 1ull);
-      if (!__ballot(use)) {
-        wv.cnt_shadow += N * (uint32_t)__popcll(__ballot(hit));
+      use_m &= ~cand.umbra;
+      use = lane_of(use_m);
+      if (!use_m) {
+        wv.cnt_shadow += N * (uint32_t)__popcll(hit_m);
         continue;
       }
     }
@@ -1205,7 +1184,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         if (use && j + 1 < N) cnext = cs[j + 1];
       }
       V3 ltp = lp - sf.p;
-      wv.cnt_shadow += (uint32_t)__popcll(__ballot(hit));
+      wv.cnt_shadow += (uint32_t)__popcll(hit_m);
       V3 ld;
       float lmag;
       Shadow S;
@@ -1217,7 +1196,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         const float rs = __builtin_amdgcn_rsqf(l2);
         ld = ltp * rs;
         lmag = l2 * rs;
-        S.occluded = false;
+        S.occ = 0ull;
         S.opacity = 1.0f;
         S.filter = mk(1.0f, 1.0f, 1.0f);
         W.s_passes++;
@@ -1237,15 +1216,16 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
           BoxRay b2 = box_ray(so2, d2);
           if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
         }
-        S = shadow_ray<CULL>(sc, P, W, use, so, ld, tmax, cand);
+        S = shadow_ray<CULL>(sc, P, W, use_m, so, ld, tmax, cand);
       }
-      bool reach = use && !S.occluded;
+      const lanemask reach_m = use_m & ~S.occ;
 #if RT_PROFILE == 3
-      set_occ += (uint32_t)__popcll(__ballot(use && S.occluded));
-      set_tot += (uint32_t)__popcll(__ballot(use));
-      set_filt += (uint32_t)__popcll(__ballot(use && !S.occluded && S.opacity < 1.0f));
+      set_occ += (uint32_t)__popcll(use_m & S.occ);
+      set_tot += (uint32_t)__popcll(use_m);
+      set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
 #endif
-      if (!__ballot(reach)) continue;
+      if (!reach_m) continue;
+      const bool reach = lane_of(reach_m);
       const unsigned long long t_l = PROF_T();
       // PointLight::calculate_contribution_at, light.rs:261-299
       float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp) above
@@ -1543,7 +1523,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       }
     }
   }
-  wave_flush(wv, P, (uint32_t)__popcll(__ballot(wrote)), lds_cnt);
+  wave_flush(wv, P, (uint32_t)__popcll(wave_ballot(wrote)), lds_cnt);
 }
 
 // __launch_bounds__(256, 4): 127 VGPRs, NO scratch.  Measured on MI355X, config 3 (this kernel):
@@ -1617,13 +1597,13 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
   if (have) r = load_queued_ray(P, (size_t)P.q_in_first + i);
   V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
   bool alive = have && !has_nan(d);
-  unsigned long long bal = __ballot(alive);
+  unsigned long long bal = wave_ballot(alive);
   Hit h;
   h.t = INFINITY;
   h.id = -1;
   if (bal) {
-    wv.cnt_kind[1] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (uint32_t)__popcll(__ballot(alive && r.kind == KIND_REFR));
+    wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
+    wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
     wv.cnt_pass += 1;
     wv.cnt_lanes += (uint32_t)__popcll(bal);
     h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
