@@ -44,12 +44,7 @@
 
 #define RT_EPS 1.1920929e-7f
 
-// Diagnostic builds only (make ABLATE=n): RT_DOUBLE bit i repeats one component's arithmetic with an
-// opaque copy of its inputs, so the time delta of the build IS that component's share of the kernel
-// (control flow and results unchanged).  Never set in the shipped library.
-#ifndef RT_DOUBLE
-#define RT_DOUBLE 0
-#endif
+// keeps a value opaque to the optimiser (no forwarding / CSE across this point)
 #define RT_OPAQUE(v) asm volatile("" : "+v"(v))
 // Lane mask of a predicate.  HIP's __ballot(int) first widens the bool to an int in a VGPR and compares it back
 // (v_cndmask + v_cmp per vote); the builtin takes the i1 as it is (the compare result already is the mask).
@@ -66,6 +61,17 @@ typedef unsigned long long lanemask;
 #endif
 #ifndef RT_SKIP
 #define RT_SKIP 0
+#endif
+// Work statistics (rt_stats.wave_*: node visits, triangle tests, wave passes) are compiled in only by
+// `make STATS=1` (librt_hip_stats.so, tools/perf_ab.py): 9 live SGPRs and an s_add per node / triangle
+// that the shipped kernels do not pay for.  The ray counters (rays_*, pixels_written) are always on.
+#ifndef RT_WORK_STATS
+#define RT_WORK_STATS 0
+#endif
+#if RT_WORK_STATS || RT_PROFILE
+#define WSTAT(stmt) stmt
+#else
+#define WSTAT(stmt) ((void)0)
 #endif
 #if RT_PROFILE == 1
 #define PROF_T() __builtin_readcyclecounter()
@@ -301,7 +307,7 @@ __device__ __forceinline__ lanemask tri_hit(float4 q0, float4 q1, float4 q2, V3 
     on &= ~(wave_ballot(xbs < -RT_TRI_G * st) | wave_ballot(xbs - tl_ad > RT_TRI_G * (st + tl_ad)));
     if (!on) return 0ull;
   }
-  n_exact++;
+  WSTAT(n_exact++);
   // ---- phase 2: literal -----------------------------------------------------------------------------
   float inv_det = 1.0f / det_i;
   V3 r0 = x * inv_det, r1 = y * inv_det, r2 = z * inv_det;
@@ -459,7 +465,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
     uint32_t node = 0;
     for (;;) {
       const RtNode nd = uload(&sc.nodes[node]);
-      W.n_nodes++;
+      WSTAT(W.n_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
       box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
@@ -469,7 +475,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       bool in0 = false, in1 = false;  // internal children to descend into
       if (b0) {
         if (nd.n0) {
-          W.n_tris += nd.n0;
+          WSTAT(W.n_tris += nd.n0);
           for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, b0);
         } else {
           in0 = true;
@@ -477,7 +483,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       }
       if (b1) {
         if (nd.n1) {
-          W.n_tris += nd.n1;
+          WSTAT(W.n_tris += nd.n1);
           for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, b1);
         } else {
           in1 = true;
@@ -697,7 +703,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     uint32_t stk = 0, sp = 0, node = 0;
     for (;;) {
       const RtNode nd = uload(&nodes[node]);
-      W.s_nodes++;
+      WSTAT(W.s_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
       if (UNI) {
@@ -798,6 +804,8 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   RT_OPAQUE(S.opacity);
 #endif
   PROF_ADD(W, 3, t_sph);
+  const unsigned long long t_tri = PROF_T();
+  (void)t_tri;
 
   auto test_tri = [&](uint32_t slot, lanemask lanes) {
     float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
@@ -820,16 +828,20 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return S;
   }
-  W.s_passes++;
+  WSTAT(W.s_passes++);
 
   if (cand.count != RT_CAND_OVERFLOW) {
     // soft shadows: test the triangle slots collected once for this (wavefront, light)
-    W.s_tris += cand.count;
+    WSTAT(W.s_tris += cand.count);
     for (uint32_t c = 0; c < cand.count; c++) {
       if (!(grp & ~S.occ)) break;
       uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)cand.reg, (int)c);
       test_tri(slot, grp);
     }
+#if RT_PROFILE
+    RT_OPAQUE(S.opacity);
+#endif
+    PROF_ADD(W, 4, t_tri);
     return S;
   }
 
@@ -844,7 +856,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       const lanemask live = grp & ~S.occ;
       if (!live) break;
       const RtNode nd = uload(&sc.nodes[node]);
-      W.s_nodes++;
+      WSTAT(W.s_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
       box_pair(nd, br, tl, h0, h1, tn0, tn1);
@@ -854,7 +866,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       bool in0 = false, in1 = false;
       if (b0) {
         if (nd.n0) {
-          W.s_tris += nd.n0;
+          WSTAT(W.s_tris += nd.n0);
           for (uint32_t k = 0; k < nd.n0; k++) test_tri(nd.c0 + k, b0);
         } else {
           in0 = true;
@@ -862,7 +874,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       }
       if (b1) {
         if (nd.n1) {
-          W.s_tris += nd.n1;
+          WSTAT(W.s_tris += nd.n1);
           for (uint32_t k = 0; k < nd.n1; k++) test_tri(nd.c1 + k, b1);
         } else {
           in1 = true;
@@ -1040,8 +1052,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     wv.cnt_kind[0] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_PRIMARY));
     wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
     wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
-    wv.cnt_pass += 1;
-    wv.cnt_lanes += (uint32_t)__popcll(bal);
+    WSTAT(wv.cnt_pass += 1);
+    WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
     const unsigned long long t_n = PROF_T();
     h = nearest_hit<CULL>(sc, P, W, alive, r.o, d);
 #if RT_PROFILE
@@ -1199,23 +1211,12 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         S.occ = 0ull;
         S.opacity = 1.0f;
         S.filter = mk(1.0f, 1.0f, 1.0f);
-        W.s_passes++;
+        WSTAT(W.s_passes++);
       } else {
         lmag = mag(ltp);
         ld = ltp * (1.0f / lmag);  // normalize(ltp)
         V3 so = sf.p + ld * epsv;
         float tmax = mag(lp - so);
-        if (RT_DOUBLE & 16) {  // diagnostic: repeat the shadow-ray set-up arithmetic
-          V3 lp2 = lp;
-          RT_OPAQUE(lp2.x);
-          V3 ltp2 = lp2 - sf.p;
-          V3 ld2 = normalize(ltp2);
-          V3 so2 = sf.p + ld2 * epsv;
-          float tmax2 = mag(lp2 - so2);
-          V3 d2 = normalize(ld2);
-          BoxRay b2 = box_ray(so2, d2);
-          if (tmax2 + b2.inv.x + b2.noi.y == 123.456f) tmax = tmax2;
-        }
         S = shadow_ray<CULL>(sc, P, W, use_m, so, ld, tmax, cand);
       }
       const lanemask reach_m = use_m & ~S.occ;
@@ -1246,20 +1247,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       }
       float light_factor = diff * cint * S.opacity;
       float spec_factor = cint * S.opacity * specf;
-      if (RT_DOUBLE & 8) {  // diagnostic: repeat the per-light contribution arithmetic
-        V3 ltq = ltp;
-        RT_OPAQUE(ltq.x);
-        float dist2 = mag(ltq) + RT_EPS;
-        float cosi2 = dot(ltq, sf.n) / dist2;
-        float att2 = 0.95f * (RT_EPS + dist2 + dist2 * dist2);
-        float sig2 = (tanhf(att2) + 1.0f) / 2.0f;
-        float lf2 = cosi2 * lI * clampf(sig2, 0.0f, 1.0f);
-        V3 Lc2 = (mcolor * lc) / (S.filter + mk(dist2, dist2, dist2) * 0.0f);
-        V3 ld3 = normalize(ltq);
-        V3 rr2 = normalize(reflected(ld3, sf.n));
-        float sp2 = has_spec ? powf(fmaxf(dot(rr2, d), 0.0f), fmaxf(mshin * 512.0f, 1.0f)) : 0.0f;
-        if (lf2 + Lc2.x + Lc2.y + Lc2.z + sp2 == 123.456f) light_factor += 1.0f;
-      }
       if (reach && diff > 0.0f) {
         light_color = light_color + (mcolor * Lc) * light_factor;
         if (has_spec) spec_color = spec_color + lc * spec_factor;
@@ -1604,8 +1591,8 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
   if (bal) {
     wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
     wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
-    wv.cnt_pass += 1;
-    wv.cnt_lanes += (uint32_t)__popcll(bal);
+    WSTAT(wv.cnt_pass += 1);
+    WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
     h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
   }
   if (have) {

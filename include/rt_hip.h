@@ -158,7 +158,9 @@ typedef struct rt_stats {
   uint64_t pixels_written;
   double kernel_ms; /* device time of the render kernel(s) (CPU oracle: wall time) */
   double total_ms;  /* wall time of the call incl. copies */
-  /* GPU only (0 from the CPU oracle): SIMD efficiency of the ray loop.  wave_ray_passes = number of
+  /* The wave_* work statistics below are filled only by the statistics build of the library
+   * (`make STATS=1` -> librt_hip_stats.so, used by tools/perf_ab.py); the shipped kernels leave them 0.
+   * GPU only (0 from the CPU oracle): SIMD efficiency of the ray loop.  wave_ray_passes = number of
    * wavefront-level trips through cast_ray + shading; wave_ray_lanes = live lanes summed over those
    * trips.  lanes / (64 * passes) = fraction of the 64-wide machine doing useful ray work. */
   uint64_t wave_ray_passes;

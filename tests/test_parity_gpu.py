@@ -333,6 +333,51 @@ def test_random_scene_shadows_only_dense():
     compare(cfg, flat, (60, 50, 48, 40))
 
 
+def test_umbra_penumbra_and_horizon_classification():
+    """Beam-level shortcuts of the soft-shadow path against the brute-force oracle where they all trigger: a floor
+    under an opaque and a glass occluder (full umbra, penumbra bands, filtered light), a light below the floor's
+    horizon, a light almost in the floor plane (grazing), and a sphere resting on the floor (rays leaving their
+    own sphere)."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import FlatScene
+    f32 = np.float32
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], width_override=200, height_override=160,
+                                     n_cloud_sets=8, cloud_seed=3)
+    sh, sd = float(cfg.scene_height), float(cfg.scene_depth)
+    mats = np.asarray([[0.8, 0.8, 0.7, 0, 0.2, 1, 0, 0, 0],       # floor
+                       [0.9, 0.2, 0.2, 0, 0.4, 1, 0, 0, 0],       # opaque occluder
+                       [0.3, 0.9, 0.5, 0, 0.3, 1.5, 0.7, 0.1, 1],  # glass occluder
+                       [0.4, 0.5, 0.9, 0.3, 0.5, 1, 0, 0, 0]], f32)
+    # the "floor" is a slanted plane rising with depth (so that it fills the lower half of the image)
+    c0, a0, b0 = np.asarray([0.0, 0.85 * sh, 0.05 * sd]), np.asarray([1.0, 0.0, 0.0]), np.asarray([0.0, -0.45 * sh, 0.9 * sd])
+    up = np.cross(a0, b0)
+    up /= np.linalg.norm(up)  # towards the camera
+
+    def on_plane(u, v, lift=0.0):
+        return c0 + u * a0 + v * b0 + lift * up
+
+    quads = [  # (corner, e1, e2, material)
+        (c0, a0, b0, 0),
+        (on_plane(0.25, 0.35, 0.12), 0.25 * a0, 0.25 * b0, 1),
+        (on_plane(0.60, 0.40, 0.08), 0.20 * a0 + 0.01 * up, 0.20 * b0, 2),
+    ]
+    v1, e1, e2, nrm, mid = [], [], [], [], []
+    for c, a, b, m in quads:
+        c, a, b = np.asarray(c, f32), np.asarray(a, f32), np.asarray(b, f32)
+        n = np.cross(a, b)
+        n = (n / np.linalg.norm(n)).astype(f32)
+        for (p0, u, v) in ((c, a, b), (c + a + b, -a, -b)):
+            v1.append(p0), e1.append(u), e2.append(v), nrm.append(n), mid.append(m)
+    sc = np.asarray([on_plane(0.5, 0.78, 0.05)], f32)
+    sr = np.asarray([0.05], f32)
+    lights = np.asarray([[*on_plane(0.45, 0.45, 0.5), 1, 1, 1, 0.7],       # above the occluders
+                         [*on_plane(0.15, 0.30, 0.004), 1, 0.9, 0.8, 0.5],  # grazing: almost in the floor plane
+                         [*on_plane(0.70, 0.50, -0.2), 0.8, 0.9, 1, 0.6]], f32)  # below the floor's horizon
+    flat = FlatScene(sc, (sr * sr).astype(f32), (1 / sr).astype(f32), np.asarray([3], np.uint32),
+                     np.asarray(v1, f32), np.asarray(e1, f32), np.asarray(e2, f32), np.asarray(nrm, f32),
+                     np.asarray(mid, np.uint32), mats, lights)
+    compare(cfg, flat, (30, 70, 140, 60))
+
+
 def test_ray_streaming_with_tiny_chunks(monkeypatch):
     """Forces many primary batches and multi-chunk queue levels (RT_CHUNK_LOG2 = 10 -> 1024 rays per
     launch): the deepest-first drain and the queue-capacity invariant must give the same image."""

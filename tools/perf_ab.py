@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Quick kernel timing for A/B work (not the official metric): renders named workloads (optionally a
+"""Quick kernel timing for A/B work (not the official metric; the per-wave work statistics need
+RT_HIP_LIB=.../librt_hip_stats.so, built by `make STATS=1` in csrc): renders named workloads (optionally a
 window) through rt_render_device with HBM-resident buffers and prints kernel ms + ray rates.
 Usage: perf_ab.py [c3|c4|c2|default][:x0,y0,w,h] ... [--reps N]"""
 import ctypes as C
@@ -65,13 +66,7 @@ for spec in args or ["c3"]:
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
           f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
-    if os.environ.get("RT_HIP_LIB", "").endswith("_prof4.so"):
-        # make PROFILE=4 build: inside candidate collection (wave-level shader-clock cycles)
-        n_sets = max(1, st.wave_shadow_passes // max(1, cfg.point_light_multiplicator))
-        print(f"{'':28s} per collection: total {st.wave_nearest_tris_exact/n_sets:.0f} cycles = sphere mask {st.wave_nearest_nodes/n_sets:.0f} + node loop "
-              f"{st.wave_nearest_tris/n_sets:.0f} + leaf triangles {st.wave_shadow_nodes/n_sets:.0f}; nodes {st.wave_shadow_tris_exact/n_sets:.1f}, "
-              f"leaf triangles {st.wave_shadow_tris/n_sets:.1f}; whole ray {st.wave_ray_lanes/max(1, st.wave_ray_passes):.0f} cycles")
-    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
+    if os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
         # make PROFILE=3 build: outcome of the candidate sets that had something to test
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
              st.wave_shadow_tris_exact]
