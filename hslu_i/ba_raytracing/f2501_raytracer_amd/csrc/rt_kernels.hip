@@ -1101,6 +1101,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   // ---- calculate_lighting, raytracer_renderer.rs:731-874 ----------------------------------------
   V3 light_color = mk(0, 0, 0), spec_color = mk(0, 0, 0);
   const bool has_spec = mshin > 0.0f;
+  // every hit point casts lights x N shadow rays in the reference (raytracer.rs:24); counted here once, whatever
+  // part of them the classifications below resolve without a traversal
+  wv.cnt_shadow += sc.n_lights * N * (uint32_t)__popcll(hit_m);
   for (uint32_t l = 0; l < sc.n_lights; l++) {
     const float4 L0 = uload(&sc.lights[2 * l + 0]);
     const float4 L1 = uload(&sc.lights[2 * l + 1]);
@@ -1130,7 +1133,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     }
     lanemask use_m = wave_ballot(use);
     if (!use_m) {
-      wv.cnt_shadow += N * (uint32_t)__popcll(hit_m);
       continue;
     }
     CandList cand;
@@ -1172,8 +1174,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       use_m &= ~cand.umbra;
       use = lane_of(use_m);
       if (!use_m) {
-        wv.cnt_shadow += N * (uint32_t)__popcll(hit_m);
-        continue;
+          continue;
       }
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
@@ -1196,7 +1197,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         if (use && j + 1 < N) cnext = cs[j + 1];
       }
       V3 ltp = lp - sf.p;
-      wv.cnt_shadow += (uint32_t)__popcll(hit_m);
       V3 ld;
       float lmag;
       Shadow S;
