@@ -69,7 +69,7 @@ struct rt_scene {
   int device = 0;
   RtDevScene dev{};
   rt_bvh_info info{};
-  DevBuf spheres, sphere_mat, tri_isect, tri_shade, tri_id, materials, lights, nodes, nodes_oct;
+  DevBuf blob;  // spheres, triangles, materials, lights, BVH (RtDevScene offsets)
   // per-render workspaces
   DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
   std::vector<uint32_t> sup_host;
@@ -95,8 +95,7 @@ int rt_device_count(void) {
 void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (DevBuf* b : {&s->spheres, &s->sphere_mat, &s->tri_isect, &s->tri_shade, &s->tri_id, &s->materials,
-                    &s->lights, &s->nodes, &s->nodes_oct, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -142,6 +141,16 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
 
   const uint32_t ns = d->n_spheres, nt = d->n_triangles;
   int rc;
+  // All scene arrays live in ONE device allocation (`blob`): the kernels address them as base + 32-bit byte
+  // offset, which the scalar loads take as an SGPR offset (2 scalar instructions per address instead of 4, and
+  // one base pointer instead of nine in SGPRs).
+  std::vector<unsigned char> blob;
+  auto put = [&](uint32_t* off, const void* src, size_t bytes) {
+    blob.resize((blob.size() + 255) / 256 * 256);
+    *off = (uint32_t)blob.size();
+    if (bytes) blob.insert(blob.end(), (const unsigned char*)src, (const unsigned char*)src + bytes);
+    blob.resize(blob.size() + 64);  // the widest scalar load may read past the last record
+  };
   {
     // {cx, cy, cz, r_sq} per sphere, then one float per sphere: an upper bound of the radius (candidate culling)
     std::vector<float> sp(5 * (size_t)ns);
@@ -152,8 +161,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       sp[4 * i + 3] = d->sphere_r_sq[i];
       sp[4 * (size_t)ns + i] = std::sqrt(std::fabs(d->sphere_r_sq[i])) * (1.0f + 4e-7f);
     }
-    if ((rc = upload(s->spheres, sp.data(), sp.size() * 4)) != RT_OK) return bail(rc);
-    if ((rc = upload(s->sphere_mat, d->sphere_material, (size_t)ns * 4)) != RT_OK) return bail(rc);
+    put(&s->dev.off_spheres, sp.data(), 16 * (size_t)ns);
+    put(&s->dev.off_sphere_rad, sp.data() + 4 * (size_t)ns, 4 * (size_t)ns);
+    put(&s->dev.off_sphere_mat, d->sphere_material, (size_t)ns * 4);
   }
   RtBvh bvh;
   std::vector<uint8_t> no_split(nt, 0);  // = transmissive
@@ -195,13 +205,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       q[8] = e2[2], q[9] = X[0], q[10] = X[1], q[11] = X[2];
       put_shade(slot, t);
     }
-    if ((rc = upload(s->tri_isect, isect.data(), isect.size() * 4)) != RT_OK) return bail(rc);
-    if ((rc = upload(s->tri_shade, shade.data(), shade.size() * 4)) != RT_OK) return bail(rc);
+    put(&s->dev.off_tri_isect, isect.data(), isect.size() * 4);
+    put(&s->dev.off_tri_shade, shade.data(), shade.size() * 4);
     std::vector<uint32_t> ids(bvh.tri_order);
     for (uint32_t slot = 0; slot < n_slots; slot++)
       if (no_split[ids[slot] & ~RT_TRI_DUPLICATE]) ids[slot] |= RT_TRI_TRANSMISSIVE;
-    if ((rc = upload(s->tri_id, ids.data(), (size_t)n_slots * 4)) != RT_OK) return bail(rc);
-    if ((rc = upload(s->nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
+    put(&s->dev.off_tri_id, ids.data(), (size_t)n_slots * 4);
+    put(&s->dev.off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode));
     {
       // per-octant copies for the soft-shadow candidate walk: planes pre-selected (lo = entry, hi = exit), the
       // child that is entered first along the octant's diagonal stored first
@@ -233,7 +243,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
           }
           oct[o * nn + i] = d0;
         }
-      if ((rc = upload(s->nodes_oct, oct.data(), oct.size() * sizeof(RtNode))) != RT_OK) return bail(rc);
+      put(&s->dev.off_nodes_oct, oct.data(), oct.size() * sizeof(RtNode));
     }
   }
   {
@@ -245,7 +255,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       o[4] = r[RT_MAT_SHININESS], o[5] = r[RT_MAT_IOR], o[6] = r[RT_MAT_OPACITY], o[7] = r[RT_MAT_BOOST];
       o[8] = r[RT_MAT_HAS_OPACITY];
     }
-    if ((rc = upload(s->materials, m.data(), m.size() * 4)) != RT_OK) return bail(rc);
+    put(&s->dev.off_materials, m.data(), m.size() * 4);
     std::vector<float> l(8 * (size_t)d->n_lights, 0.f);
     for (uint32_t i = 0; i < d->n_lights; i++) {
       const float* r = d->lights + (size_t)i * RT_LIGHT_STRIDE;
@@ -253,19 +263,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       o[0] = r[0], o[1] = r[1], o[2] = r[2], o[3] = r[6];
       o[4] = r[3], o[5] = r[4], o[6] = r[5];
     }
-    if ((rc = upload(s->lights, l.data(), l.size() * 4)) != RT_OK) return bail(rc);
+    put(&s->dev.off_lights, l.data(), l.size() * 4);
   }
   if ((rc = s->counters.ensure(RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
 
-  s->dev.spheres = (const float4*)s->spheres.p;
-  s->dev.sphere_mat = (const uint32_t*)s->sphere_mat.p;
-  s->dev.tri_isect = (const float4*)s->tri_isect.p;
-  s->dev.tri_shade = (const float4*)s->tri_shade.p;
-  s->dev.tri_id = (const uint32_t*)s->tri_id.p;
-  s->dev.materials = (const float4*)s->materials.p;
-  s->dev.lights = (const float4*)s->lights.p;
-  s->dev.nodes_oct = (const RtNode*)s->nodes_oct.p;
-  s->dev.nodes = (const RtNode*)s->nodes.p;
+  if (blob.size() >= (size_t)1 << 32) return bail(fail(RT_ERR_UNSUPPORTED, "scene data exceeds 4 GiB"));
+  if ((rc = upload(s->blob, blob.data(), blob.size())) != RT_OK) return bail(rc);
+  s->dev.base = (const char*)s->blob.p;
   s->dev.n_spheres = ns;
   s->dev.n_triangles = nt;
   s->dev.n_slots = n_slots;

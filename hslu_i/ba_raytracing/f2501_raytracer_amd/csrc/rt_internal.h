@@ -53,17 +53,20 @@ void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8
 
 // ---- kernel argument block ---------------------------------------------------------------------
 struct RtDevScene {
-  const float4* spheres;
-  const uint32_t* sphere_mat;
-  const float4* tri_isect;
-  const float4* tri_shade;
-  const uint32_t* tri_id;
-  const float4* materials;
-  const float4* lights;
-  const RtNode* nodes;
+  // One allocation; every array is addressed as base + 32-bit byte offset (an SGPR offset of the scalar loads).
+  const char* base;
+  uint32_t off_spheres;     // float4 {cx, cy, cz, r_sq}
+  uint32_t off_sphere_rad;  // float: upper bound of the radius (candidate culling)
+  uint32_t off_sphere_mat;  // uint32 material row
+  uint32_t off_tri_isect;   // 3 x float4 per leaf slot {v1.xyz, e1.x} {e1.yz, e2.xy} {e2.z, X.xyz}
+  uint32_t off_tri_shade;   // float4 {normal, material} per leaf slot, then per canonical triangle
+  uint32_t off_tri_id;      // uint32 per leaf slot: canonical index | RT_TRI_* flags
+  uint32_t off_materials;   // 3 x float4
+  uint32_t off_lights;      // 2 x float4
+  uint32_t off_nodes;       // RtNode
   // 8 copies of nodes, one per direction octant o (bit a = direction negative along axis a): lo* hold the entry
   // planes and hi* the exit planes for that octant, children are in near-first order (octant o: [o * n_nodes ...])
-  const RtNode* nodes_oct;
+  uint32_t off_nodes_oct;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
   uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
 };

@@ -136,6 +136,18 @@ __device__ __forceinline__ T uload(const T* p) {
   return v;
 }
 
+// Scene arrays: one allocation, base + 32-bit byte offset (rt_internal.h).  sload: wave-uniform offset ->
+// `s_load_dwordx* sdst, s[base], soffset` (the offset is an SGPR operand of the load: no 64-bit address
+// arithmetic); vload: per-lane offset.
+template <class T>
+__device__ __forceinline__ T sload(const RtDevScene& sc, uint32_t byte_off) {
+  return uload((const T*)(sc.base + byte_off));
+}
+template <class T>
+__device__ __forceinline__ T vload(const RtDevScene& sc, uint32_t byte_off) {
+  return *(const T*)(sc.base + byte_off);
+}
+
 // ---- colour-only arithmetic ----------------------------------------------------------------------
 // Quantities that feed ONLY the RGB value (never a hit / occlusion / spawn decision) use the
 // hardware's 1-ulp reciprocal / rsqrt instead of the IEEE division / sqrt sequences (44 and 57
@@ -169,9 +181,9 @@ struct Mat {
 };
 
 __device__ __forceinline__ Mat load_mat(const RtDevScene& sc, uint32_t idx) {
-  const float4 a = sc.materials[3 * idx + 0];
-  const float4 b = sc.materials[3 * idx + 1];
-  const float4 c = sc.materials[3 * idx + 2];
+  const float4 a = vload<float4>(sc, sc.off_materials + idx * 48u);
+  const float4 b = vload<float4>(sc, sc.off_materials + idx * 48u + 16u);
+  const float4 c = vload<float4>(sc, sc.off_materials + idx * 48u + 32u);
   Mat m;
   m.color = mk(a.x, a.y, a.z);
   m.metallic = a.w;
@@ -185,9 +197,9 @@ __device__ __forceinline__ Mat load_mat(const RtDevScene& sc, uint32_t idx) {
 
 // same, material index wave-uniform
 __device__ __forceinline__ Mat load_mat_u(const RtDevScene& sc, uint32_t idx) {
-  const float4 a = uload(&sc.materials[3 * idx + 0]);
-  const float4 b = uload(&sc.materials[3 * idx + 1]);
-  const float4 c = uload(&sc.materials[3 * idx + 2]);
+  const float4 a = sload<float4>(sc, sc.off_materials + idx * 48u);
+  const float4 b = sload<float4>(sc, sc.off_materials + idx * 48u + 16u);
+  const float4 c = sload<float4>(sc, sc.off_materials + idx * 48u + 32u);
   Mat m;
   m.color = mk(a.x, a.y, a.z);
   m.metallic = a.w;
@@ -408,13 +420,13 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   best.t = INFINITY;
   best.id = -1;
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
-    float4 s = uload(&sc.spheres[i]);
+    float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
     float t;
     bool h = alive && sphere_hit(s, o, d, t);
     if (CULL && h) {  // sphere.rs:137-151
       V3 p = fma_s(d, t, o);
       V3 n = normalize(p - mk(s.x, s.y, s.z));
-      Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
+      Mat m = load_mat_u(sc, sload<uint32_t>(sc, sc.off_sphere_mat + i * 4u));
       h = (dot(d, n) < 0.75f) || m.transmissive;
     }
     if (h && t <= best.t) {
@@ -426,20 +438,20 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   const int tri_base = (int)sc.n_spheres;
 
   auto test_tri = [&](uint32_t slot, lanemask lanes) {
-    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
-    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
-    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+    float4 q0 = sload<float4>(sc, sc.off_tri_isect + slot * 48u);
+    float4 q1 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 16u);
+    float4 q2 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 32u);
     float t;
     lanemask h = tri_hit(q0, q1, q2, o, d, lanes, best.t, t, W.n_exact);
     if (CULL) {  // triangle.rs:154-168
       if (h) {
-        float4 sh = uload(&sc.tri_shade[slot]);
+        float4 sh = sload<float4>(sc, sc.off_tri_shade + slot * 16u);
         Mat m = load_mat_u(sc, __float_as_uint(sh.w));
         if (!m.transmissive) h &= wave_ballot(dot(d, mk(sh.x, sh.y, sh.z)) < 0.75f);
       }
     }
     if (h) {
-      int id = tri_base + (int)(uload(&sc.tri_id[slot]) & RT_TRI_INDEX_MASK);
+      int id = tri_base + (int)(sload<uint32_t>(sc, sc.off_tri_id + slot * 4u) & RT_TRI_INDEX_MASK);
       if (lane_of(h) && (t < best.t || (t == best.t && id > best.id))) {
         best.t = t;
         best.id = id;
@@ -451,7 +463,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     // the literal scan visits every triangle once: skip the extra references of split triangles
     for (uint32_t s = 0; s < sc.n_slots; s++)
-      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, grp);
+      if (!(sload<uint32_t>(sc, sc.off_tri_id + s * 4u) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return best;
   }
 
@@ -464,7 +476,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
     uint32_t sp = 0;
     uint32_t node = 0;
     for (;;) {
-      const RtNode nd = uload(&sc.nodes[node]);
+      const RtNode nd = sload<RtNode>(sc, sc.off_nodes + node * 64u);
       WSTAT(W.n_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
@@ -604,9 +616,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
   // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
   auto beam_rejects_all = [&](uint32_t slot, lanemask lanes) -> bool {
-    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
-    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
-    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+    float4 q0 = sload<float4>(sc, sc.off_tri_isect + slot * 48u);
+    float4 q1 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 16u);
+    float4 q2 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 32u);
     V3 c1 = mk(-q0.w, -q1.x, -q1.y), c2 = mk(-q1.z, -q1.w, -q2.x), x = mk(q2.y, q2.z, q2.w);
     V3 b = mk(q0.x, q0.y, q0.z) - p;
     float det = dot(dseg, x);
@@ -640,7 +652,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     // literal test would accept it for each j (u_j, v_j >= 0, u_j + v_j < 1, EPS < t_j <= tmax_j, |det_j| > EPS,
     // all by margins that cover the rounding of the literal sequence), so the lane is occluded for this light
     // whatever else lies on the way: none of its samples needs to be traced.
-    if (!CULL && !(uload(&sc.tri_id[slot]) & RT_TRI_TRANSMISSIVE)) {
+    if (!CULL && !(sload<uint32_t>(sc, sc.off_tri_id + slot * 4u) & RT_TRI_TRANSMISSIVE)) {
       const float dlo = ad - dslack;
       const float r_hi = lenp * __builtin_amdgcn_rcpf(dlo) * 1.00001f;                 // >= |D_j| / |D_j.X|
       const float r_lo = (len - delta) * __builtin_amdgcn_rcpf(ad + dslack) * 0.99999f;  // <= |D_j| / |D_j.X|
@@ -662,16 +674,15 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // whose centre is farther than r + delta from that segment cannot be touched by any of them
   {
     uint32_t mask = 0;
-    const float* sph_rad = (const float*)(sc.spheres + sc.n_spheres);  // host-computed radius bounds
     const float inv_len2 = __builtin_amdgcn_rcpf(fmaxf(dot(dseg, dseg), 1e-30f));
     const uint32_t ns = sc.n_spheres < 32u ? sc.n_spheres : 32u;
     for (uint32_t i = 0; i < ns; i++) {
-      float4 sp4 = uload(&sc.spheres[i]);
+      float4 sp4 = sload<float4>(sc, sc.off_spheres + i * 16u);
       V3 w = mk(sp4.x, sp4.y, sp4.z) - p;
       const float wd = dot(w, dseg);
       float sp = clampf(wd * inv_len2, 0.0f, 1.0f);
       V3 q = w - dseg * sp;
-      float reach = uload(&sph_rad[i]) + delta;
+      float reach = sload<float>(sc, sc.off_sphere_rad + i * 4u) + delta;
       bool near = dot(q, q) <= reach * reach * 1.0002f + 1e-12f;
       // Leaving rays: with v_j = so_j - centre and unit d_j, sphere_hit has no root >= 0 when cc_j = |v_j|^2 - r^2
       // is positive by more than the rounding of disc = b^2 - 4 cc (b^2 <= 4 |v|^2) and d_j.v_j > 0.  Over the beam
@@ -695,14 +706,14 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   // no ordering vote.  Mixed octants: the generic slab test and a vote, on the original nodes.
   auto walk = [&](auto uni_tag) {
     constexpr bool UNI = decltype(uni_tag)::value;
-    const RtNode* nodes = sc.nodes;
+    uint32_t nodes_off = sc.off_nodes;
     if (UNI) {
       const uint32_t oct = (mx ? 1u : 0u) | (my ? 2u : 0u) | (mz ? 4u : 0u);
-      nodes = sc.nodes_oct + (size_t)__builtin_amdgcn_readfirstlane(oct) * sc.n_nodes;
+      nodes_off = sc.off_nodes_oct + __builtin_amdgcn_readfirstlane(oct) * sc.n_nodes * 64u;
     }
     uint32_t stk = 0, sp = 0, node = 0;
     for (;;) {
-      const RtNode nd = uload(&nodes[node]);
+      const RtNode nd = sload<RtNode>(sc, nodes_off + node * 64u);
       WSTAT(W.s_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
@@ -786,7 +797,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   const unsigned long long t_sph = PROF_T();
   for (uint32_t i = 0; i < sc.n_spheres; i++) {
     if (i < 32u && !((cand.spheres >> i) & 1u)) continue;  // culled for this (wavefront, light)
-    float4 s = uload(&sc.spheres[i]);
+    float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
     float t = 0.0f;
     lanemask h = grp & ~S.occ & wave_ballot(sphere_hit(s, o, d, t));
     h &= wave_ballot(t <= tmax);
@@ -794,7 +805,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       // (computed for every lane, applied to the lanes in h: keeps S.occ a wave-uniform mask)
       V3 p = fma_s(d, t, o);
       V3 n = normalize(p - mk(s.x, s.y, s.z));
-      Mat m = load_mat_u(sc, uload(&sc.sphere_mat[i]));
+      Mat m = load_mat_u(sc, sload<uint32_t>(sc, sc.off_sphere_mat + i * 4u));
       if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
       shadow_accumulate(S, m, n, d, h);
     }
@@ -808,14 +819,14 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   (void)t_tri;
 
   auto test_tri = [&](uint32_t slot, lanemask lanes) {
-    float4 q0 = uload(&sc.tri_isect[3 * slot + 0]);
-    float4 q1 = uload(&sc.tri_isect[3 * slot + 1]);
-    float4 q2 = uload(&sc.tri_isect[3 * slot + 2]);
+    float4 q0 = sload<float4>(sc, sc.off_tri_isect + slot * 48u);
+    float4 q1 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 16u);
+    float4 q2 = sload<float4>(sc, sc.off_tri_isect + slot * 48u + 32u);
     float t;
     lanemask h = tri_hit(q0, q1, q2, o, d, lanes & ~S.occ, tmax, t, W.s_exact);
     h &= wave_ballot(t <= tmax);
     if (h) {
-      float4 sh = uload(&sc.tri_shade[slot]);
+      float4 sh = sload<float4>(sc, sc.off_tri_shade + slot * 16u);
       Mat m = load_mat_u(sc, __float_as_uint(sh.w));
       V3 n = mk(sh.x, sh.y, sh.z);
       if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
@@ -825,7 +836,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
 
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     for (uint32_t s = 0; s < sc.n_slots; s++)
-      if (!(uload(&sc.tri_id[s]) & RT_TRI_DUPLICATE)) test_tri(s, grp);
+      if (!(sload<uint32_t>(sc, sc.off_tri_id + s * 4u) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return S;
   }
   WSTAT(W.s_passes++);
@@ -855,7 +866,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     for (;;) {
       const lanemask live = grp & ~S.occ;
       if (!live) break;
-      const RtNode nd = uload(&sc.nodes[node]);
+      const RtNode nd = sload<RtNode>(sc, sc.off_nodes + node * 64u);
       WSTAT(W.s_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
@@ -914,12 +925,12 @@ __device__ __forceinline__ Surf surface_of(const RtDevScene& sc, Hit h, V3 o, V3
   Surf s;
   s.p = fma_s(d, h.t, o);
   if (h.id < (int)sc.n_spheres) {
-    float4 sp = sc.spheres[h.id];
+    float4 sp = vload<float4>(sc, sc.off_spheres + (uint32_t)h.id * 16u);
     s.n = normalize(s.p - mk(sp.x, sp.y, sp.z));
-    s.mat = sc.sphere_mat[h.id];
+    s.mat = vload<uint32_t>(sc, sc.off_sphere_mat + (uint32_t)h.id * 4u);
   } else {
     // tri_shade holds a canonical-order copy behind the leaf-order one for this lookup (rt_api.cpp)
-    float4 sh = sc.tri_shade[sc.n_slots + (uint32_t)(h.id - (int)sc.n_spheres)];
+    float4 sh = vload<float4>(sc, sc.off_tri_shade + (sc.n_slots + (uint32_t)(h.id - (int)sc.n_spheres)) * 16u);
     s.n = mk(sh.x, sh.y, sh.z);
     s.mat = __float_as_uint(sh.w);
   }
@@ -1105,8 +1116,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   // part of them the classifications below resolve without a traversal
   wv.cnt_shadow += sc.n_lights * N * (uint32_t)__popcll(hit_m);
   for (uint32_t l = 0; l < sc.n_lights; l++) {
-    const float4 L0 = uload(&sc.lights[2 * l + 0]);
-    const float4 L1 = uload(&sc.lights[2 * l + 1]);
+    const float4 L0 = sload<float4>(sc, sc.off_lights + l * 32u);
+    const float4 L1 = sload<float4>(sc, sc.off_lights + l * 32u + 16u);
     const V3 lc = mk(L1.x, L1.y, L1.z);
     const float4* cs = nullptr;
     float lI = L0.w;
