@@ -1192,55 +1192,13 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #if RT_PROFILE == 3
     uint32_t set_occ = 0, set_tot = 0, set_filt = 0;
 #endif
-    // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
-    // the load latency hides under a whole shadow traversal
-    float4 cnext = make_float4(0, 0, 0, 0);
-    if (N > 1 && use) cnext = cs[0];
-    for (uint32_t j = 0; j < N; j++) {
-#if RT_PROFILE
-      W.t_mark = PROF_T();
-#endif
-      V3 lp = mk(L0.x, L0.y, L0.z);
-      if (N > 1) {
-        lp.x = L0.x + cnext.x;  // light.rs:218; the table holds offset * (fw, fh, fd)
-        lp.y = L0.y + cnext.y;
-        lp.z = L0.z + cnext.z;
-        if (use && j + 1 < N) cnext = cs[j + 1];
-      }
-      V3 ltp = lp - sf.p;
-      V3 ld;
-      float lmag;
-      Shadow S;
-      if (nothing) {
-        // no triangle and no sphere can touch any sample ray of this (wavefront, light): the shadow ray is
-        // known to arrive, so its origin / length / re-normalised direction (3 IEEE sqrt, 2 IEEE div) are not
-        // needed; what is left of ld and |ltp| only scales the colour
-        const float l2 = dot(ltp, ltp);
-        const float rs = __builtin_amdgcn_rsqf(l2);
-        ld = ltp * rs;
-        lmag = l2 * rs;
-        S.occ = 0ull;
-        S.opacity = 1.0f;
-        S.filter = mk(1.0f, 1.0f, 1.0f);
-        WSTAT(W.s_passes++);
-      } else {
-        lmag = mag(ltp);
-        ld = ltp * (1.0f / lmag);  // normalize(ltp)
-        V3 so = sf.p + ld * epsv;
-        float tmax = mag(lp - so);
-        S = shadow_ray<CULL>(sc, P, W, use_m, so, ld, tmax, cand);
-      }
-      const lanemask reach_m = use_m & ~S.occ;
-#if RT_PROFILE == 3
-      set_occ += (uint32_t)__popcll(use_m & S.occ);
-      set_tot += (uint32_t)__popcll(use_m);
-      set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
-#endif
-      if (!reach_m) continue;
+    // PointLight::calculate_contribution_at, light.rs:261-299, for the lanes in reach_m.  FILTERED = false: the
+    // shadow ray is known to arrive untouched (opacity 1, filter 1): no filter divisions.
+    auto add_light = [&](auto filtered_tag, V3 ltp, V3 ld, float lmag, const Shadow& S, lanemask reach_m) {
+      constexpr bool FILTERED = decltype(filtered_tag)::value;
       const bool reach = lane_of(reach_m);
       const unsigned long long t_l = PROF_T();
-      // PointLight::calculate_contribution_at, light.rs:261-299
-      float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp) above
+      float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp)
       float cosi = fast_div(dot(ltp, sf.n), dist);
       bool pos = cosi > 0.0f;
       float att = 0.95f * (RT_EPS + dist + dist * dist);
@@ -1248,7 +1206,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       float lf = cosi * lI * clampf(sig, 0.0f, 1.0f);
       V3 ccol = pos ? (mcolor * lc) : mk(0, 0, 0);
       float cint = pos ? lf : 0.0f;
-      V3 Lc = mk(fast_div(ccol.x, S.filter.x), fast_div(ccol.y, S.filter.y), fast_div(ccol.z, S.filter.z));
+      V3 Lc = ccol;
+      if (FILTERED) Lc = mk(fast_div(ccol.x, S.filter.x), fast_div(ccol.y, S.filter.y), fast_div(ccol.z, S.filter.z));
       float diff = fmaxf(dot(sf.n, ld), 0.0f);
       float specf = 0.0f;
       if (has_spec) {
@@ -1256,8 +1215,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         float base = fmaxf(dot(rr, d), 0.0f);
         specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
       }
-      float light_factor = diff * cint * S.opacity;
-      float spec_factor = cint * S.opacity * specf;
+      float light_factor = FILTERED ? diff * cint * S.opacity : diff * cint;
+      float spec_factor = FILTERED ? cint * S.opacity * specf : cint * specf;
       if (reach && diff > 0.0f) {
         light_color = light_color + (mcolor * Lc) * light_factor;
         if (has_spec) spec_color = spec_color + lc * spec_factor;
@@ -1266,6 +1225,57 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       RT_OPAQUE(light_color.x);
 #endif
       PROF_ADD(W, 5, t_l);
+    };
+    // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
+    // the load latency hides under a whole shadow traversal
+    float4 cnext = make_float4(0, 0, 0, 0);
+    if (N > 1 && use) cnext = cs[0];
+    auto light_position = [&](uint32_t j) {
+      V3 lp = mk(L0.x, L0.y, L0.z);
+      if (N > 1) {
+        lp.x = L0.x + cnext.x;  // light.rs:218; the table holds offset * (fw, fh, fd)
+        lp.y = L0.y + cnext.y;
+        lp.z = L0.z + cnext.z;
+        if (use && j + 1 < N) cnext = cs[j + 1];
+      }
+      return lp;
+    };
+    if (nothing) {
+      // no triangle and no sphere can touch any sample ray of this (wavefront, light): the shadow rays are
+      // known to arrive, so their origin / length / re-normalised direction (3 IEEE sqrt, 2 IEEE div per
+      // sample) are not needed; what is left of ld and |ltp| only scales the colour
+      Shadow S;
+      S.occ = 0ull;
+      S.opacity = 1.0f;
+      S.filter = mk(1.0f, 1.0f, 1.0f);
+      for (uint32_t j = 0; j < N; j++) {
+        const V3 ltp = light_position(j) - sf.p;
+        const float l2 = dot(ltp, ltp);
+        const float rs = __builtin_amdgcn_rsqf(l2);
+        WSTAT(W.s_passes++);
+        add_light(std::false_type{}, ltp, ltp * rs, l2 * rs, S, use_m);
+      }
+    } else {
+      for (uint32_t j = 0; j < N; j++) {
+#if RT_PROFILE
+        W.t_mark = PROF_T();
+#endif
+        const V3 lp = light_position(j);
+        const V3 ltp = lp - sf.p;
+        const float lmag = mag(ltp);
+        const V3 ld = ltp * (1.0f / lmag);  // normalize(ltp)
+        const V3 so = sf.p + ld * epsv;
+        const float tmax = mag(lp - so);
+        const Shadow S = shadow_ray<CULL>(sc, P, W, use_m, so, ld, tmax, cand);
+        const lanemask reach_m = use_m & ~S.occ;
+#if RT_PROFILE == 3
+        set_occ += (uint32_t)__popcll(use_m & S.occ);
+        set_tot += (uint32_t)__popcll(use_m);
+        set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
+#endif
+        if (!reach_m) continue;
+        add_light(std::true_type{}, ltp, ld, lmag, S, reach_m);
+      }
     }
 #if RT_PROFILE == 3  // outcome of the (wavefront, light) sets that had something to test
     if (!nothing && set_tot) {

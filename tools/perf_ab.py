@@ -47,6 +47,8 @@ for spec in args or ["c3"]:
         flat = dataclasses.replace(flat, lights=flat.lights[: int(os.environ["RT_AB_LIGHTS"])])
     ds = DeviceScene(flat, 0)
     p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank)
+    if os.environ.get("RT_AB_TILE"):  # experiments: ownership tile size of the multi-GPU partition
+        p.tile_size = int(os.environ["RT_AB_TILE"])
     fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
     times = []
     for r in range(reps + 1):
