@@ -378,6 +378,36 @@ def test_umbra_penumbra_and_horizon_classification():
     compare(cfg, flat, (30, 70, 140, 60))
 
 
+def test_config3_full_size_properties(monkeypatch):
+    """BASELINE.json configs[2] at its full size (1620x1350, 16 rays/px, 5 x 10 shadow rays per hit, text.obj):
+    size-independent properties instead of the (hours-long) brute-force oracle --
+    determinism, the multi-GPU tile partition, and the whole soft-shadow machinery (shared candidate lists, beam
+    rejection, umbra / horizon / arrival shortcuts) against the plain per-sample BVH walk of the same kernel."""
+    cfg = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"])
+    flat = scenes.semesterbild(cfg, "text").flatten()
+    a0, p0, s0 = gpu_render(cfg, flat)
+    assert s0["rays_primary"] == cfg.width * cfg.height * cfg.aa_total_rays
+    n_hits = s0["rays_shadow"] // (5 * cfg.point_light_multiplicator)
+    assert s0["rays_shadow"] == n_hits * 5 * cfg.point_light_multiplicator and 0 < n_hits <= s0["rays_primary"]
+    a1, _, _ = gpu_render(cfg, flat)
+    assert np.array_equal(a0, a1), "render is not deterministic"
+    acc = np.zeros_like(a0)
+    for rank in range(3):
+        ar, _, _ = gpu_render(cfg, flat, n_ranks=3, rank=rank)
+        assert not (acc[ar != 0] != 0).any(), "tiles of two ranks overlap"
+        acc |= ar
+    assert np.array_equal(acc, a0), "union of the ranks' tiles differs from the single-GPU frame"
+    monkeypatch.setenv("RT_CAND_MAX", "0")  # every (wavefront, light) overflows: one BVH walk per sample, no shortcuts
+    a2, p2, s2 = gpu_render(cfg, flat)
+    monkeypatch.delenv("RT_CAND_MAX")
+    assert np.array_equal(p2["hit_id"], p0["hit_id"]) and np.array_equal(p2["hit_t"], p0["hit_t"])
+    assert s2["rays_shadow"] == s0["rays_shadow"]
+    d = np.abs(p2["rgb"] - p0["rgb"]).max()
+    assert d <= 2e-6, d
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    assert np.abs(ch(a2) - ch(a0)).max() <= 1
+
+
 def test_ray_streaming_with_tiny_chunks(monkeypatch):
     """Forces many primary batches and multi-chunk queue levels (RT_CHUNK_LOG2 = 10 -> 1024 rays per
     launch): the deepest-first drain and the queue-capacity invariant must give the same image."""
