@@ -782,7 +782,8 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   return L;
 }
 
-template <bool CULL>
+// LIST: the caller has checked (once per light, not once per sample) that a shared candidate list exists
+template <bool CULL, bool LIST>
 __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
                                              lanemask grp, V3 o, V3 d_raw, float tmax, const CandList& cand) {
   Shadow S;
@@ -795,8 +796,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   PROF_ADD(W, 2, W.t_mark);
 #endif
   const unsigned long long t_sph = PROF_T();
-  for (uint32_t i = 0; i < sc.n_spheres; i++) {
-    if (i < 32u && !((cand.spheres >> i) & 1u)) continue;  // culled for this (wavefront, light)
+  auto test_sphere = [&](uint32_t i) {
     float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
     float t = 0.0f;
     lanemask h = grp & ~S.occ & wave_ballot(sphere_hit(s, o, d, t));
@@ -809,8 +809,12 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
       shadow_accumulate(S, m, n, d, h);
     }
-  }
-  if (sc.n_triangles == 0) return S;
+  };
+  // spheres 0..31 through the bits of the (wavefront, light) mask, in index order; any further ones unconditionally
+  for (uint32_t bits = cand.spheres & (sc.n_spheres >= 32u ? 0xFFFFFFFFu : ((1u << sc.n_spheres) - 1u)); bits; bits &= bits - 1u)
+    test_sphere((uint32_t)__builtin_ctz(bits));
+  for (uint32_t i = 32u; i < sc.n_spheres; i++) test_sphere(i);
+  if (!LIST && sc.n_triangles == 0) return S;
 #if RT_PROFILE
   RT_OPAQUE(S.opacity);
 #endif
@@ -834,14 +838,14 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     }
   };
 
-  if (P.traversal == RT_TRAVERSAL_LINEAR) {
+  if (!LIST && P.traversal == RT_TRAVERSAL_LINEAR) {
     for (uint32_t s = 0; s < sc.n_slots; s++)
       if (!(sload<uint32_t>(sc, sc.off_tri_id + s * 4u) & RT_TRI_DUPLICATE)) test_tri(s, grp);
     return S;
   }
   WSTAT(W.s_passes++);
 
-  if (cand.count != RT_CAND_OVERFLOW) {
+  if (LIST) {
     // soft shadows: test the triangle slots collected once for this (wavefront, light)
     WSTAT(W.s_tris += cand.count);
     for (uint32_t c = 0; c < cand.count; c++) {
@@ -1256,26 +1260,33 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         add_light(std::false_type{}, ltp, ltp * rs, l2 * rs, S, use_m);
       }
     } else {
-      for (uint32_t j = 0; j < N; j++) {
+      auto traced_samples = [&](auto list_tag) {
+        for (uint32_t j = 0; j < N; j++) {
 #if RT_PROFILE
-        W.t_mark = PROF_T();
+          W.t_mark = PROF_T();
 #endif
-        const V3 lp = light_position(j);
-        const V3 ltp = lp - sf.p;
-        const float lmag = mag(ltp);
-        const V3 ld = ltp * (1.0f / lmag);  // normalize(ltp)
-        const V3 so = sf.p + ld * epsv;
-        const float tmax = mag(lp - so);
-        const Shadow S = shadow_ray<CULL>(sc, P, W, use_m, so, ld, tmax, cand);
-        const lanemask reach_m = use_m & ~S.occ;
+          const V3 lp = light_position(j);
+          const V3 ltp = lp - sf.p;
+          const float lmag = mag(ltp);
+          const V3 ld = ltp * (1.0f / lmag);  // normalize(ltp)
+          const V3 so = sf.p + ld * epsv;
+          const float tmax = mag(lp - so);
+          const Shadow S = shadow_ray<CULL, decltype(list_tag)::value>(sc, P, W, use_m, so, ld, tmax, cand);
+          const lanemask reach_m = use_m & ~S.occ;
 #if RT_PROFILE == 3
-        set_occ += (uint32_t)__popcll(use_m & S.occ);
-        set_tot += (uint32_t)__popcll(use_m);
-        set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
+          set_occ += (uint32_t)__popcll(use_m & S.occ);
+          set_tot += (uint32_t)__popcll(use_m);
+          set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
 #endif
-        if (!reach_m) continue;
-        add_light(std::true_type{}, ltp, ld, lmag, S, reach_m);
-      }
+          if (!reach_m) continue;
+          add_light(std::true_type{}, ltp, ld, lmag, S, reach_m);
+        }
+      };
+      // (decided once per light: per-sample uniform branches cost issue slots and mask registers)
+      if (cand.count != RT_CAND_OVERFLOW && P.traversal != RT_TRAVERSAL_LINEAR && sc.n_triangles)
+        traced_samples(std::true_type{});
+      else
+        traced_samples(std::false_type{});
     }
 #if RT_PROFILE == 3  // outcome of the (wavefront, light) sets that had something to test
     if (!nothing && set_tot) {
