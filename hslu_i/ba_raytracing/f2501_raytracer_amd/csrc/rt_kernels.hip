@@ -46,6 +46,9 @@
 
 // keeps a value opaque to the optimiser (no forwarding / CSE across this point)
 #define RT_OPAQUE(v) asm volatile("" : "+v"(v))
+// same for a wave-uniform value: gives it an SGPR of its own (kernel arguments arrive in 8/16-dword tuples, and
+// hipcc spills and reloads a tuple as a whole -- 8 v_readlane to get at one of its fields inside a loop)
+#define RT_OPAQUE_S(v) asm volatile("" : "+s"(v))
 // Lane mask of a predicate.  HIP's __ballot(int) first widens the bool to an int in a VGPR and compares it back
 // (v_cndmask + v_cmp per vote); the builtin takes the i1 as it is (the compare result already is the mask).
 #define wave_ballot(pred) __builtin_amdgcn_ballot_w64((bool)(pred))
@@ -552,6 +555,7 @@ struct CandList {
 template <bool CULL>
 __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
                                                               const RtDevParams& P, uint32_t cand_cap) {
+  RT_OPAQUE_S(cand_cap);
   const float delta = P.beam_delta;
   CandList L;
   L.reg = 0;
