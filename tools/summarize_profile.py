@@ -46,7 +46,8 @@ if "GRBM_GUI_ACTIVE" in pmc:
     out.append(f"* effective clock {clk:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / time)")
     if "SQ_ACTIVE_INST_VALU" in pmc:
         vb = pmc["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (pmc["GRBM_GUI_ACTIVE"] / 8)
-        out.append(f"* VALUBusy = SQ_ACTIVE_INST_VALU*4 / 1024 SIMDs / cycles = {100*vb:.1f} %")
+        out.append(f"* VALUBusy = SQ_ACTIVE_INST_VALU*4 / 1024 SIMDs / cycles = {100*vb:.1f} %"
+                   + (" (the guide's 4-cycles-per-instruction convention; > 100 % means VALU instructions retire faster than that)" if vb > 1.0 else ""))
 if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
     out.append(f"* VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU*64) = "
                f"{100*pmc['SQ_THREAD_CYCLES_VALU']/(pmc['SQ_ACTIVE_INST_VALU']*64):.1f} %")
