@@ -422,7 +422,35 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   Hit best;
   best.t = INFINITY;
   best.id = -1;
-  for (uint32_t i = 0; i < sc.n_spheres; i++) {
+  const lanemask grp = wave_ballot(alive);
+  // Sphere pre-selection across lanes (coherent packets: camera rays, sorted secondary rays): lane i looks at
+  // sphere i and the ray of the wavefront's first lane.  A point of ray l at parameter t is within
+  // so + t * sd of ray 0's point at t (so, sd = spread of the origins / unit directions over the wavefront), and a
+  // hit lies at t <= |c - o_l| + r, so sphere i can only be hit by some lane if its centre is within
+  // r + so + (|c - o_0| + so + r) * sd of ray 0.  One test for all spheres; the survivors are tested per lane.
+  uint32_t pre = 0xFFFFFFFFu;
+  if (sc.n_spheres > 2u && grp) {
+    const uint32_t ns = sc.n_spheres < 32u ? sc.n_spheres : 32u;
+    const int fl = __ffsll((long long)grp) - 1;
+    auto first = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), fl)); };
+    const V3 o0 = mk(first(o.x), first(o.y), first(o.z)), d0 = mk(first(d.x), first(d.y), first(d.z));
+    const V3 eo = o - o0, ed = d - d0;
+    float so = alive ? fabsf(eo.x) + fabsf(eo.y) + fabsf(eo.z) : 0.0f, sd = alive ? fabsf(ed.x) + fabsf(ed.y) + fabsf(ed.z) : 0.0f;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+      so = fmaxf(so, __shfl_xor(so, k, 64));
+      sd = fmaxf(sd, __shfl_xor(sd, k, 64));
+    }
+    const uint32_t lane = threadIdx.x & 63u, si = lane < ns ? lane : ns - 1u;
+    const float4 sp = vload<float4>(sc, sc.off_spheres + si * 16u);
+    const float rad = vload<float>(sc, sc.off_sphere_rad + si * 4u);
+    const V3 w = mk(sp.x, sp.y, sp.z) - o0;
+    const float tc = fmaxf(dot(w, d0), 0.0f);
+    const V3 q = w - d0 * tc;
+    const float reach = rad + so + (mag(w) + so + rad) * sd * 1.0001f + 1e-6f;
+    pre = (uint32_t)(wave_ballot(dot(q, q) <= reach * reach * 1.0002f) & ((1ull << ns) - 1ull));
+  }
+  auto test_sphere = [&](uint32_t i) {
     float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
     float t;
     bool h = alive && sphere_hit(s, o, d, t);
@@ -436,7 +464,11 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       best.t = t;
       best.id = (int)i;
     }
-  }
+  };
+  // in index order (ties go to the later object, raytracer.rs:193-213)
+  for (uint32_t bits = pre & (sc.n_spheres >= 32u ? 0xFFFFFFFFu : ((1u << sc.n_spheres) - 1u)); bits; bits &= bits - 1u)
+    test_sphere((uint32_t)__builtin_ctz(bits));
+  for (uint32_t i = 32u; i < sc.n_spheres; i++) test_sphere(i);
   if (sc.n_triangles == 0) return best;
   const int tri_base = (int)sc.n_spheres;
 
@@ -462,7 +494,6 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
     }
   };
 
-  const lanemask grp = wave_ballot(alive);
   if (P.traversal == RT_TRAVERSAL_LINEAR) {
     // the literal scan visits every triangle once: skip the extra references of split triangles
     for (uint32_t s = 0; s < sc.n_slots; s++)
@@ -474,18 +505,46 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
   const uint32_t lane_id = threadIdx.x & 63u;
   // The traversal stack is ONE stack per wavefront, held in the 64 lanes of a single VGPR
   // (push = select on lane id, pop = v_readlane with a scalar lane index): no LDS round trip.
-  {
+  // Coherent wavefronts (all camera packets, most sorted secondary packets) point into one direction
+  // octant: they walk that octant's copy of the tree (entry / exit planes pre-selected, children stored
+  // near-first): 12 fma + max3/min3 per node and no ordering vote.
+  // (sign of the clamped reciprocal, so that -0 components agree with the slab arithmetic)
+  const lanemask ox = wave_ballot(br.inv.x < 0.0f) & grp, oy = wave_ballot(br.inv.y < 0.0f) & grp, oz = wave_ballot(br.inv.z < 0.0f) & grp;
+  const bool octant_uniform = (ox == 0 || ox == grp) && (oy == 0 || oy == grp) && (oz == 0 || oz == grp);
+  auto walk = [&](auto uni_tag) {
+    constexpr bool UNI = decltype(uni_tag)::value;
+    uint32_t nodes_off = sc.off_nodes;
+    if (UNI) {
+      const uint32_t oct = (ox ? 1u : 0u) | (oy ? 2u : 0u) | (oz ? 4u : 0u);
+      nodes_off = sc.off_nodes_oct + __builtin_amdgcn_readfirstlane(oct) * sc.n_nodes * 64u;
+    }
     uint32_t stk = 0;
     uint32_t sp = 0;
     uint32_t node = 0;
     for (;;) {
-      const RtNode nd = sload<RtNode>(sc, sc.off_nodes + node * 64u);
+      const RtNode nd = sload<RtNode>(sc, nodes_off + node * 64u);
       WSTAT(W.n_nodes++);
       float tn0, tn1;
       lanemask h0, h1;
-      box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
-      const lanemask b0 = nd.c0 != RT_NODE_EMPTY ? (h0 & grp) : 0ull;
-      const lanemask b1 = nd.c1 != RT_NODE_EMPTY ? (h1 & grp) : 0ull;
+      if (UNI) {
+        const float tls = t_limit_slack(best.t);
+        tn0 = fmaxf(fmaxf(__builtin_fmaf(nd.lo0[0], br.inv.x, br.noi.x), __builtin_fmaf(nd.lo0[1], br.inv.y, br.noi.y)),
+                    __builtin_fmaf(nd.lo0[2], br.inv.z, br.noi.z));
+        tn1 = fmaxf(fmaxf(__builtin_fmaf(nd.lo1[0], br.inv.x, br.noi.x), __builtin_fmaf(nd.lo1[1], br.inv.y, br.noi.y)),
+                    __builtin_fmaf(nd.lo1[2], br.inv.z, br.noi.z));
+        const float tm0 = fminf(fminf(__builtin_fmaf(nd.hi0[0], br.inv.x, br.noi.x), __builtin_fmaf(nd.hi0[1], br.inv.y, br.noi.y)),
+                                __builtin_fmaf(nd.hi0[2], br.inv.z, br.noi.z));
+        const float tm1 = fminf(fminf(__builtin_fmaf(nd.hi1[0], br.inv.x, br.noi.x), __builtin_fmaf(nd.hi1[1], br.inv.y, br.noi.y)),
+                                __builtin_fmaf(nd.hi1[2], br.inv.z, br.noi.z));
+        const float s0 = __builtin_fmaf(fabsf(tm0), 4e-6f, tm0 + 1e-5f), s1 = __builtin_fmaf(fabsf(tm1), 4e-6f, tm1 + 1e-5f);
+        h0 = wave_ballot(tn0 <= fminf(s0, tls)) & wave_ballot(s0 >= 0.0f);
+        h1 = wave_ballot(tn1 <= fminf(s1, tls)) & wave_ballot(s1 >= 0.0f);
+      } else {
+        box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
+      }
+      // (an absent child has an inverted box in every copy: never hit)
+      const lanemask b0 = h0 & grp;
+      const lanemask b1 = h1 & grp;
       uint32_t next = RT_NODE_EMPTY;
       bool in0 = false, in1 = false;  // internal children to descend into
       if (b0) {
@@ -505,10 +564,13 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
         }
       }
       if (in0 && in1) {
-        // near-first by wave vote among lanes that hit both children
-        const unsigned long long both = b0 & b1;
-        const unsigned long long pref1 = wave_ballot(tn1 < tn0) & both;
-        const bool first1 = 2 * __popcll(pref1) > __popcll(both);
+        bool first1 = false;
+        if (!UNI) {
+          // near-first by wave vote among lanes that hit both children
+          const lanemask both = b0 & b1;
+          const lanemask pref1 = wave_ballot(tn1 < tn0) & both;
+          first1 = 2 * __popcll(pref1) > __popcll(both);
+        }
         stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;  // push: lane `sp` of the stack register
         sp++;
         next = first1 ? nd.c1 : nd.c0;
@@ -524,7 +586,11 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       }
       node = next;
     }
-  }
+  };
+  if (octant_uniform)
+    walk(std::true_type{});
+  else
+    walk(std::false_type{});
   return best;
 }
 
