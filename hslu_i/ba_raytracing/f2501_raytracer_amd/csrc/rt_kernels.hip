@@ -161,15 +161,11 @@ __device__ __forceinline__ V3 fast_normalize(V3 a) {
   return a * r;
 }
 
-// tanh(x) for x >= 0 and pow(b, e) for b in [0, 1], e >= 1 with the hardware exp2 / log2 instead of
-// ocml's tanhf / powf (colour-only factors: light sigmoid, specular lobe).  Measured: -7.5 % kernel
-// time on config 3; max |dRGB| vs the oracle over the whole parity suite 3.7e-6 (7e-7 with ocml; bar
+// The light sigmoid (tanh(x) + 1) / 2 = 1 / (1 + exp(-2x)) and pow(b, e) for b in [0, 1], e >= 1 use the hardware
+// exp2 / log2 / rcp instead of ocml's tanhf / powf (colour-only factors).  Measured: -7.5 % kernel time on
+// config 3 when introduced; max |dRGB| vs the oracle over the whole parity suite < 4e-6 (7e-7 with ocml; bar
 // 1e-4).  The reference itself evaluates both with `wide`'s polynomial approximations.
 // -DRT_FAST_TRANS=0 selects ocml.
-__device__ __forceinline__ float fast_tanh_pos(float x) {
-  float e = __builtin_amdgcn_exp2f(x * -2.885390082f);  // exp(-2x)
-  return (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-}
 __device__ __forceinline__ float fast_pow01(float b, float e) {
   return b > 0.0f ? __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(b)) : 0.0f;
 }
@@ -1311,8 +1307,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       const float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp)
       const float diff = dot(sf.n, ld);  // = cosi
       const float att = 0.95f * (RT_EPS + dist + dist * dist);
-      const float sig = ((RT_FAST_TRANS ? fast_tanh_pos(att) : tanhf(att)) + 1.0f) / 2.0f;
-      const float cint = diff * lI * clampf(sig, 0.0f, 1.0f);
+      // (tanh(att) + 1) / 2 = 1 / (1 + exp(-2 att)): one exp2 and one rcp; already inside [0, 1]
+      const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(att * -2.885390082f))
+                                      : clampf((tanhf(att) + 1.0f) / 2.0f, 0.0f, 1.0f);
+      const float cint = diff * lI * sig;
       V3 Lc = mc_lc;
       if (FILTERED) Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
       float specf = 0.0f;
