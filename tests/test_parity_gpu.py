@@ -325,6 +325,15 @@ def test_random_scenes_all_features(seed):
     compare(cfg, flat, ((13 * seed) % 100, (7 * seed) % 80, 56, 40))
 
 
+def test_more_than_32_spheres():
+    """The per-(wavefront, light) sphere mask and the lane-parallel sphere pre-selection cover spheres 0..31; the
+    ones beyond are tested unconditionally.  40 spheres, soft shadows, secondary rays."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160,
+                                     height_override=128, n_cloud_sets=8, depth_override=2, cloud_seed=5)
+    flat = random_scene(23, n_spheres=40, n_tris=120, n_lights=2, cfg=cfg)
+    compare(cfg, flat, (40, 30, 64, 48))
+
+
 def test_random_scene_shadows_only_dense():
     """Same, many small triangles and big light clouds, no secondary rays (the headline kernel path)."""
     cfg = RenderConfig.from_features(["anti_aliasing", "high_quality"], width_override=192, height_override=160,
