@@ -131,3 +131,22 @@ class RaytracerRenderer:
         _lib.check(lib.rt_render(ds.handle, C.byref(p), buffer.buffer.ctypes.data, C.byref(a) if aux else None, C.byref(st)))
         self.last_stats = st.as_dict()
         return planes
+
+    def render_progressive(self, buffer: ImageBuffer, scene, on_tiles=None, rows_per_step: Optional[int] = None):
+        """Progressive display (reference `Renderer::render` fills the shared u32 buffer tile by tile while the
+        window shows it, renderer/mod.rs:84-209, output/window.rs): the frame is rendered in horizontal bands of
+        `rows_per_step` tile rows (default: one row of RENDER_STRIDE tiles) and `on_tiles(buffer, (x0, y0, w, h))`
+        is called after each band has landed in `buffer`.  The result equals one `render` call (the window
+        parameter of the C ABI renders exactly the pixels inside it).  Returns the number of bands."""
+        cfg = self.cfg
+        ts = cfg.render_stride
+        step = ts * (rows_per_step if rows_per_step else 1)
+        n = 0
+        for y0 in range(0, cfg.height, step):
+            win = (0, y0, cfg.width, min(step, cfg.height - y0))
+            self.render(buffer, scene, window=win)
+            n += 1
+            if on_tiles is not None:
+                on_tiles(buffer, win)
+        return n
+

@@ -417,6 +417,21 @@ def test_config3_full_size_properties(monkeypatch):
     assert np.abs(ch(a2) - ch(a0)).max() <= 1
 
 
+def test_progressive_bands_equal_one_render():
+    """`render_progressive` (the reference's tile-by-tile fill of the shared buffer) ends with the same buffer as one
+    `render`, and reports every band once."""
+    cfg = RenderConfig.from_features(["reflections", "anti_aliasing"])
+    flat = scenes.test_scene(cfg).flatten()
+    full, _, _ = gpu_render(cfg, flat)
+    buf = ImageBuffer.new(cfg.width, cfg.height)
+    seen = []
+    r = RaytracerRenderer(cfg, device=0)
+    n = r.render_progressive(buf, flat, on_tiles=lambda b, w: seen.append((w, int((b.buffer != 0).sum()))))
+    assert n == len(seen) == -(-cfg.height // cfg.render_stride)
+    assert all(seen[i][1] <= seen[i + 1][1] for i in range(len(seen) - 1))  # the picture only grows
+    assert np.array_equal(buf.buffer, full)
+
+
 def test_ray_streaming_with_tiny_chunks(monkeypatch):
     """Forces many primary batches and multi-chunk queue levels (RT_CHUNK_LOG2 = 10 -> 1024 rays per
     launch): the deepest-first drain and the queue-capacity invariant must give the same image."""
