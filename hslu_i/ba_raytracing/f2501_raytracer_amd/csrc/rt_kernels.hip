@@ -1263,9 +1263,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       RT_OPAQUE(cand.reg);
 #endif
       PROF_ADD(W, 1, t_c);
-#if RT_SKIP  // removal ablation (timing only, wrong image): 1 no shadow sphere tests, 2 no shadow triangle tests
+#if RT_SKIP  // removal ablation (timing only, wrong image): 1 no shadow sphere tests, 2 no shadow triangle tests,
+            // 8 sets whose shared list overflows are treated as having nothing to test
       if (RT_SKIP & 1) cand.spheres = 0;
       if (RT_SKIP & 2) cand.count = 0;
+      if ((RT_SKIP & 8) && cand.count == RT_CAND_OVERFLOW) cand.count = 0, cand.spheres = 0;
 #endif
 #if RT_PROFILE == 2  // histogram of (wavefront, light) candidate sets instead of timers
       {
