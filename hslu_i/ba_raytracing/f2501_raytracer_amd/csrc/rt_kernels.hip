@@ -1226,7 +1226,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       uint32_t tix = threadIdx.x;
       RT_OPAQUE(tix);  // a real LDS read per light instead of a register held through the loop
       const uint32_t pixel = __float_as_uint(stash[9u * 256u + tix]);
-      uint32_t set = rt_cloud_hash(P.cloud_seed, pixel, l) % P.n_cloud_sets;
+      const uint32_t hsh = rt_cloud_hash(P.cloud_seed, pixel, l);
+      // (a power-of-two table -- the default 1024 -- needs no integer division: ~25 vector instructions per light)
+      const uint32_t set = (P.n_cloud_sets & (P.n_cloud_sets - 1u)) == 0u ? (hsh & (P.n_cloud_sets - 1u)) : (hsh % P.n_cloud_sets);
       cs = P.cloud_sets + (size_t)set * N;
       lI = (1.0f / (float)N) * L0.w;
     }
