@@ -1319,7 +1319,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       if (FILTERED) Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
       float specf = 0.0f;
       if (has_spec) {
-        V3 rr = fast_normalize(reflected(ld, sf.n));
+        // reflected(ld, n) = ld - 2 (ld.n) n with ld.n = diff; a reflection keeps the length, and the shading
+        // normal enters only through n / |n|^2 -- the reference normalises the result, here |n| = 1 is not assumed:
+        const V3 rr = fast_normalize(fma_s(sf.n, -2.0f * diff, ld));
         float base = fmaxf(dot(rr, d), 0.0f);
         specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
       }
