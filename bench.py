@@ -229,7 +229,7 @@ def main():
                 "traffic": pmc_traffic_bytes()[0] if (args.workload == "c3" and world == 1) else None,
                 "traffic_source": pmc_traffic_bytes()[1] if (args.workload == "c3" and world == 1) else None,
                 "kernel": "rt_primary_kernel", "kernel_ms": kernel_ms,
-                "note": "algorithmic 64 B/ray ray-stream model (SURVEY 8d); the kernel is VALU/latency bound, "
+                "note": "algorithmic 64 B/ray ray-stream model (SURVEY 8d); the kernel is bound by vector-instruction issue, "
                         "see DESIGN.md and profiles/",
             },
         }
