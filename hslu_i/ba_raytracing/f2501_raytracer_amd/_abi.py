@@ -5,15 +5,25 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OOM, RT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 RT_FLAG_REFLECTIONS, RT_FLAG_REFRACTIONS, RT_FLAG_BACKFACE_CULLING, RT_FLAG_ANTI_ALIASING = 1, 2, 4, 8
 RT_TRAVERSAL_BVH, RT_TRAVERSAL_LINEAR = 0, 1
+RT_CAND_CAP_NONE = 0xFFFFFFFF
 
 _fp = C.POINTER(C.c_float)
 _up = C.POINTER(C.c_uint32)
 _ip = C.POINTER(C.c_int32)
+
+
+class rt_bvh_tuning(C.Structure):
+    _fields_ = [("max_leaf", C.c_uint32), ("tri_cost", C.c_float), ("split_depth", C.c_uint32), ("split_gain", C.c_float)]
+
+
+class rt_tuning(C.Structure):
+    _fields_ = [("shadow_candidate_cap", C.c_uint32), ("chunk_log2", C.c_uint32), ("no_aa_dedup", C.c_uint32),
+                ("no_counters", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class rt_scene_desc(C.Structure):
@@ -25,6 +35,7 @@ class rt_scene_desc(C.Structure):
         ("tri_material", _up),
         ("n_materials", C.c_uint32), ("materials", _fp),
         ("n_lights", C.c_uint32), ("lights", _fp),
+        ("bvh", rt_bvh_tuning),
     ]
 
 
@@ -40,6 +51,7 @@ class rt_params(C.Structure):
         ("win_x0", C.c_uint32), ("win_y0", C.c_uint32), ("win_w", C.c_uint32), ("win_h", C.c_uint32),
         ("tile_size", C.c_uint32), ("n_ranks", C.c_uint32), ("rank", C.c_uint32),
         ("traversal", C.c_uint32),
+        ("tuning", rt_tuning),
     ]
 
 
@@ -50,8 +62,8 @@ class rt_aux(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_reflection", C.c_uint64), ("rays_refraction", C.c_uint64),
-        ("rays_shadow", C.c_uint64), ("pixels_written", C.c_uint64),
-        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("rays_shadow", C.c_uint64), ("pixels_written", C.c_uint64), ("rays_traced", C.c_uint64),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("d2h_ms", C.c_double),
         ("wave_ray_passes", C.c_uint64), ("wave_ray_lanes", C.c_uint64),
         ("wave_nearest_nodes", C.c_uint64), ("wave_nearest_tris", C.c_uint64),
         ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
@@ -79,8 +91,8 @@ def uptr(a: np.ndarray):
     return a.ctypes.data_as(_up)
 
 
-def make_scene_desc(flat):
-    """flat: FlatScene (contiguous).  Returns (desc, keepalive)."""
+def make_scene_desc(flat, bvh=None):
+    """flat: FlatScene (contiguous); bvh: dict of rt_bvh_tuning fields.  Returns (desc, keepalive)."""
     f = flat.contiguous()
     d = rt_scene_desc()
     d.abi_version = RT_ABI_VERSION
@@ -94,11 +106,13 @@ def make_scene_desc(flat):
     d.materials = fptr(f.materials)
     d.n_lights = int(f.lights.shape[0])
     d.lights = fptr(f.lights)
+    for k, v in (bvh or {}).items():
+        setattr(d.bvh, k, v)
     return d, f
 
 
-def make_params(cfg, aa_offsets=None, cloud=None, window=None, n_ranks=1, rank=0, traversal=RT_TRAVERSAL_BVH):
-    """cfg: RenderConfig.  Returns (params, keepalive)."""
+def make_params(cfg, aa_offsets=None, cloud=None, window=None, n_ranks=1, rank=0, traversal=RT_TRAVERSAL_BVH, tuning=None):
+    """cfg: RenderConfig; tuning: dict of rt_tuning fields.  Returns (params, keepalive)."""
     from . import sampling
 
     p = rt_params()
@@ -145,4 +159,6 @@ def make_params(cfg, aa_offsets=None, cloud=None, window=None, n_ranks=1, rank=0
     p.tile_size = cfg.render_stride
     p.n_ranks, p.rank = int(n_ranks), int(rank)
     p.traversal = int(traversal)
+    for k, v in (tuning or {}).items():
+        setattr(p.tuning, k, int(v))
     return p, keep

@@ -74,10 +74,19 @@ struct rt_scene {
   DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
-  size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers
+  size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
   uint32_t chunk = 1u << 16;  // rays per secondary launch / primary batch of the current frame
+  float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host, cloud_scaled;
+  std::vector<uint32_t> aa_table;  // device image: [2U] offsets (float bits), [U] multiplicities, [n] sample -> thread
+  uint32_t aa_unique = 0;
+  bool aa_dedup = true;
+  // The tables are uploaded on the stream of the call that changed them; a later call on another stream waits for
+  // that upload (tables_ev) before its kernels read them.
+  hipEvent_t tables_ev = nullptr;
+  hipStream_t tables_stream = nullptr, last_stream = nullptr;
+  bool tables_pending = false, rendered = false;
   float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
 };
@@ -95,6 +104,7 @@ int rt_device_count(void) {
 void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
   for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
@@ -173,7 +183,29 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       const float* r = d->materials + (size_t)d->tri_material[i] * RT_MATERIAL_STRIDE;
       no_split[i] = (r[RT_MAT_HAS_OPACITY] != 0.0f && !(std::fabs(r[RT_MAT_OPACITY]) <= 1.1920929e-7f)) ? 1 : 0;
     }
-    rt_build_bvh(d->tri_v1, d->tri_e1, d->tri_e2, no_split.data(), nt, &bvh);
+    rt_build_bvh(d->tri_v1, d->tri_e1, d->tri_e2, no_split.data(), nt, d->bvh, &bvh);
+  }
+  {
+    // bounds of everything a ray can hit (Morton keys of secondary hit points)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](float x, float y, float z) {
+      const float v[3] = {x, y, z};
+      for (int a = 0; a < 3; a++)
+        if (std::isfinite(v[a])) lo[a] = std::fmin(lo[a], v[a]), hi[a] = std::fmax(hi[a], v[a]);
+    };
+    for (uint32_t i = 0; i < ns; i++) {
+      const float* c = d->sphere_center + 3 * (size_t)i;
+      const float r = std::sqrt(std::fabs(d->sphere_r_sq[i]));
+      grow(c[0] - r, c[1] - r, c[2] - r), grow(c[0] + r, c[1] + r, c[2] + r);
+    }
+    for (uint32_t i = 0; i < nt; i++) {
+      const float *v = d->tri_v1 + 3 * (size_t)i, *a = d->tri_e1 + 3 * (size_t)i, *b = d->tri_e2 + 3 * (size_t)i;
+      grow(v[0], v[1], v[2]), grow(v[0] + a[0], v[1] + a[1], v[2] + a[2]), grow(v[0] + b[0], v[1] + b[1], v[2] + b[2]);
+    }
+    for (int a = 0; a < 3; a++) {
+      if (!(lo[a] <= hi[a])) lo[a] = 0.f, hi[a] = 1.f;
+      s->aabb_lo[a] = lo[a], s->aabb_hi[a] = hi[a];
+    }
   }
   const uint32_t n_slots = (uint32_t)bvh.tri_order.size();
   {
@@ -310,6 +342,10 @@ static int validate_params(const rt_params* p) {
   if (p->traversal > RT_TRAVERSAL_LINEAR) return fail(RT_ERR_INVALID_ARG, "unknown traversal mode");
   if (p->max_depth_reflection > 64 || p->max_depth_refraction > 64)
     return fail(RT_ERR_UNSUPPORTED, "recursion depth > 64");
+  if (p->tuning.shadow_candidate_cap > 64u && p->tuning.shadow_candidate_cap != RT_CAND_CAP_NONE)
+    return fail(RT_ERR_INVALID_ARG, "tuning.shadow_candidate_cap > 64");
+  if (p->tuning.chunk_log2 && (p->tuning.chunk_log2 < 10u || p->tuning.chunk_log2 > 26u))
+    return fail(RT_ERR_INVALID_ARG, "tuning.chunk_log2 outside 10..26");
   return RT_OK;
 }
 
@@ -328,14 +364,53 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   const bool aa = (p->flags & RT_FLAG_ANTI_ALIASING) && p->aa_rays > 0;
   P->aa_rays = aa ? p->aa_rays : 0;
   int rc;
+  bool uploaded = false;
+  // a table may only be overwritten once the frames that read the old one are done, and kernels on another stream
+  // may only start once the upload has landed
+  auto begin_upload = [&]() -> int {
+    if (!s->tables_ev) HIP_TRY(hipEventCreateWithFlags(&s->tables_ev, hipEventDisableTiming));
+    // (also covers the host staging vectors below: the previous asynchronous upload has read them by now)
+    if (s->tables_pending) HIP_TRY(hipStreamSynchronize(s->tables_stream));
+    if (s->rendered && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    uploaded = true;
+    return RT_OK;
+  };
+  P->aa_unique = 1;
   if (aa) {
-    size_t n = (size_t)p->aa_rays * 2;
-    if (s->aa_host.size() != n || memcmp(s->aa_host.data(), p->aa_offsets, n * 4) != 0) {
-      if ((rc = s->aa.ensure(n * 4)) != RT_OK) return rc;
-      s->aa_host.assign(p->aa_offsets, p->aa_offsets + n);
-      HIP_TRY(hipMemcpyAsync(s->aa.p, s->aa_host.data(), n * 4, hipMemcpyHostToDevice, stream));
+    const size_t n = p->aa_rays;
+    const bool dedup = !p->tuning.no_aa_dedup;
+    if (s->aa_host.size() != 2 * n || memcmp(s->aa_host.data(), p->aa_offsets, 2 * n * 4) != 0 || s->aa_dedup != dedup) {
+      // Distinct offsets in first-occurrence order.  Offsets are compared as VALUES: the origin is pixel + offset,
+      // and equal values (+0 / -0 included: the pixel coordinate is never -0) give bit-identical rays.
+      std::vector<float> uq;
+      std::vector<uint32_t> mult, src(n);
+      for (size_t k = 0; k < n; k++) {
+        const float x = p->aa_offsets[2 * k], y = p->aa_offsets[2 * k + 1];
+        size_t j = uq.size() / 2;
+        if (dedup)
+          for (j = 0; j < uq.size() / 2; j++)
+            if (uq[2 * j] == x && uq[2 * j + 1] == y) break;
+        if (j == uq.size() / 2) uq.push_back(x), uq.push_back(y), mult.push_back(0);
+        mult[j]++;
+        src[k] = (uint32_t)j;
+      }
+      const size_t U = mult.size();
+      if ((rc = begin_upload()) != RT_OK) return rc;
+      s->aa_table.resize(3 * U + n);
+      memcpy(s->aa_table.data(), uq.data(), 2 * U * 4);
+      memcpy(s->aa_table.data() + 2 * U, mult.data(), U * 4);
+      memcpy(s->aa_table.data() + 3 * U, src.data(), n * 4);
+      if ((rc = s->aa.ensure(s->aa_table.size() * 4)) != RT_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(s->aa.p, s->aa_table.data(), s->aa_table.size() * 4, hipMemcpyHostToDevice, stream));
+      s->aa_host.assign(p->aa_offsets, p->aa_offsets + 2 * n);
+      s->aa_unique = (uint32_t)U;
+      s->aa_dedup = dedup;
     }
+    P->aa_unique = s->aa_unique;
+    P->weighted = s->aa_unique != p->aa_rays;
     P->aa_offsets = (const float*)s->aa.p;
+    P->aa_mult = (const uint32_t*)s->aa.p + 2 * (size_t)s->aa_unique;
+    P->aa_src = (const uint32_t*)s->aa.p + 3 * (size_t)s->aa_unique;
   }
   P->light_mult = p->light_mult < 1 ? 1 : p->light_mult;
   P->cloud_seed = p->cloud_seed;
@@ -347,6 +422,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     if (new_table || new_scale) {
       // The device table holds the offsets already multiplied by (fw, fh, fd) (light.rs:218: the same IEEE
       // single multiply the kernel would do, done once here), one float4 per sample position.
+      if ((rc = begin_upload()) != RT_OK) return rc;
       if ((rc = s->cloud.ensure(n / 3 * 16)) != RT_OK) return rc;
       if (new_table) s->cloud_host.assign(p->cloud_sets, p->cloud_sets + n);
       s->cloud_ball[3] = -1.f;  // recompute the bounding ball
@@ -385,8 +461,8 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
       P->beam_eps_o = 1.01f * e + 2.0f * P->beam_eps_ulp;
       P->beam_eps_198 = 1.98f * e;
     }
-    P->cand_cap = 64;
-    if (const char* e = getenv("RT_CAND_MAX")) P->cand_cap = (uint32_t)atoi(e) > 64u ? 64u : (uint32_t)atoi(e);  // experiments
+    const uint32_t cap = p->tuning.shadow_candidate_cap;
+    P->cand_cap = cap == RT_CAND_CAP_NONE ? 0u : (cap ? cap : 64u);
   }
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;
@@ -407,17 +483,23 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->aux_hit_id = aux_dev->hit_id;
     P->aux_hit_t = aux_dev->hit_t;
   }
-  P->counters = getenv("RT_NO_COUNTERS") ? nullptr : (unsigned long long*)s->counters.p;  // env: experiment only
+  P->counters = p->tuning.no_counters ? nullptr : (unsigned long long*)s->counters.p;
   HIP_TRY(hipMemsetAsync(s->counters.p, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
 
   const bool aa_on = P->aa_rays > 0;
   if (aa_on && P->aa_rays > 256) return fail(RT_ERR_UNSUPPORTED, "aa_rays > 256");
+  for (int a = 0; a < 3; a++) {
+    const float ext = s->aabb_hi[a] - s->aabb_lo[a];
+    P->morton_lo[a] = s->aabb_lo[a] - 0.01f * ext;
+    P->morton_scale[a] = ext > 0.f ? 1024.0f / (1.02f * ext) : 0.f;
+  }
   // multi-GPU: launch workgroups only for the super-tiles that hold pixels of this rank's tiles
   P->sup_list = nullptr;
-  P->n_sup = 0;
+  P->n_sup = ((P->win_w + 15u) / 16u) * ((P->win_h + 15u) / 16u);
   if (P->n_ranks > 1) {
     const uint32_t key[7] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->tile_size, P->n_ranks, P->rank};
     if (memcmp(key, s->sup_key, sizeof(key)) != 0 || s->sup_host.empty()) {
+      if ((rc = begin_upload()) != RT_OK) return rc;
       s->sup_host.clear();
       const uint32_t st_x = (P->win_w + 15u) / 16u, st_y = (P->win_h + 15u) / 16u;
       for (uint32_t sy = 0; sy < st_y; sy++)
@@ -439,6 +521,15 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->sup_list = (const uint32_t*)s->suplist.p;
     P->n_sup = (uint32_t)s->sup_host.size();
   }
+  if (uploaded) {
+    HIP_TRY(hipEventRecord(s->tables_ev, stream));
+    s->tables_stream = stream;
+    s->tables_pending = true;
+  } else if (s->tables_pending && s->tables_stream != stream) {
+    HIP_TRY(hipStreamWaitEvent(stream, s->tables_ev, 0));
+  }
+  s->last_stream = stream;
+  s->rendered = true;
   return RT_OK;
 }
 
@@ -456,16 +547,20 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
 // frame's primary rays when that fits: a queue level costs 2 * chunk * 48 B, and all levels together are
 // kept under RT_QUEUE_BUDGET -- this is what 288 GB of HBM are for.  RT_CHUNK_LOG2 overrides.
 static const size_t RT_QUEUE_BUDGET = (size_t)96 << 30;
-static uint32_t choose_chunk(uint64_t primary_items, uint32_t levels) {
+// log2 of the chunk: the frame's primary work items if the queues of all levels fit the budget -- at most
+// RT_QUEUE_BUDGET and at most 60 % of the HBM that is free now plus what the scene's queues already hold (a
+// shared or partitioned device renders with smaller chunks instead of failing).  tuning.chunk_log2 overrides.
+static int choose_chunk_log2(uint64_t primary_items, uint32_t levels, size_t queues_held, uint32_t forced) {
+  if (forced) return (int)forced;
+  size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const size_t avail = (size_t)((double)(free_b + queues_held) * 0.6);
+    if (avail < budget) budget = avail;
+  }
   int lg = 16;
   while (lg < 26 && (1ull << lg) < primary_items) lg++;
-  while (lg > 16 && (size_t)levels * 2u * ((size_t)1 << lg) * 48u > RT_QUEUE_BUDGET) lg--;
-  if (const char* e = getenv("RT_CHUNK_LOG2")) {
-    lg = atoi(e);
-    if (lg < 10) lg = 10;
-    if (lg > 26) lg = 26;
-  }
-  return 1u << lg;
+  while (lg > 16 && (size_t)levels * 2u * ((size_t)1 << lg) * 48u > budget) lg--;
+  return lg;
 }
 #define RT_CHUNK (s->chunk)
 #define RT_QUEUE_CAP (2u * s->chunk)
@@ -511,7 +606,17 @@ static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels,
   return RT_OK;
 }
 
-static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream) {
+static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2);
+
+// A frame that fails half-way (queue overflow, HIP / sort / launch error, out of memory) leaves partial sums in the
+// pixel accumulator and rays in the queues: mark the accumulator dirty so that the next frame clears it.
+static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2) {
+  const int rc = render_frame_impl(s, P, stream, forced_chunk_log2);
+  if (rc != RT_OK) s->acc_pixels = 0;
+  return rc;
+}
+
+static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2) {
   const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
   const uint32_t total_wgs = rt_primary_total_wgs(P);
   if (!secondary) {
@@ -525,21 +630,27 @@ static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream) {
   int rc;
   const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
   if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
-  s->chunk = choose_chunk((uint64_t)total_wgs * 256u, levels);
   const size_t npix = (size_t)P.width * P.height;
   if (s->acc_pixels != npix) {
     if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->acc.p, 0, npix * 4 * sizeof(long long), stream));
     s->acc_pixels = npix;
   }
-  const size_t qstride = (size_t)RT_QUEUE_PLANES * RT_QUEUE_CAP;
-  if ((rc = s->queues.ensure((size_t)levels * qstride * sizeof(float4))) != RT_OK) return rc;
+  // queues: one per tree level, 2 x chunk rays each; on out-of-memory retry with half the chunk
+  int lg = choose_chunk_log2((uint64_t)total_wgs * 256u, levels, s->queues.cap, forced_chunk_log2);
+  for (;;) {
+    s->chunk = 1u << lg;
+    rc = s->queues.ensure((size_t)levels * RT_QUEUE_PLANES * RT_QUEUE_CAP * sizeof(float4));
+    if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4);
+    if (rc == RT_OK) break;
+    if (rc != RT_ERR_OOM || forced_chunk_log2 || lg <= 16) return rc;
+    lg--;
+  }
   if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
   HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));
   uint32_t* counts = (uint32_t*)s->qcount.p;  // [0] = overflow flag, [k] = rays waiting at level k
   {
     // per-chunk trace workspace: t, id, key, key', idx, idx'  (6 x RT_CHUNK dwords) + sort scratch
-    if ((rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4)) != RT_OK) return rc;
     size_t tmp_bytes = 0;
     hipError_t se = (hipError_t)rt_sort_pairs(nullptr, nullptr, nullptr, nullptr, RT_CHUNK, nullptr, &tmp_bytes, stream);
     if (se != hipSuccess) return fail(RT_ERR_HIP, "radix sort size query failed: %s", hipGetErrorString(se));
@@ -580,7 +691,7 @@ int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const 
   HIP_TRY(hipSetDevice(s->device));
   RtDevParams P;
   if ((rc = prepare(s, p, argb_dev, aux_dev, (hipStream_t)hip_stream, &P)) != RT_OK) return rc;
-  return render_frame(s, P, (hipStream_t)hip_stream);
+  return render_frame(s, P, (hipStream_t)hip_stream, p->tuning.chunk_log2);
 }
 
 int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
@@ -605,8 +716,19 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   st->wave_shadow_passes = c[11];
   st->wave_nearest_tris_exact = c[12];
   st->wave_shadow_tris_exact = c[13];
+  st->rays_traced = c[14];
   return RT_OK;
 }
+
+namespace {
+struct EventPair {  // destroyed on every return path
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+}  // namespace
 
 int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux, rt_stats* stats) {
   if (!s || !argb) return fail(RT_ERR_INVALID_ARG, "null argument");
@@ -615,50 +737,63 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
   HIP_TRY(hipSetDevice(s->device));
   auto t_begin = std::chrono::steady_clock::now();
   const size_t npix = (size_t)p->width * p->height;
+  // Only the window travels (ChunkView, image_buffer.rs:178-251): the caller's fill of its rows goes up so that
+  // miss pixels keep it (image_buffer.rs:27-37), the rendered rows come back.  A progressive band of a 1620-wide
+  // frame moves 48 rows, not the frame.
+  const uint32_t wx = p->win_w ? p->win_x0 : 0u, wy = p->win_w ? p->win_y0 : 0u;
+  const uint32_t ww = p->win_w ? p->win_w : p->width, wh = p->win_w ? p->win_h : p->height;
+  const size_t first = (size_t)wy * p->width + wx;
+  auto copy_window = [&](void* dst, const void* src, size_t bytes_per_px, hipMemcpyKind kind) -> hipError_t {
+    if (ww == p->width)  // whole rows: one contiguous block
+      return hipMemcpy((char*)dst + first * bytes_per_px, (const char*)src + first * bytes_per_px,
+                       (size_t)wh * p->width * bytes_per_px, kind);
+    return hipMemcpy2D((char*)dst + first * bytes_per_px, (size_t)p->width * bytes_per_px,
+                       (const char*)src + first * bytes_per_px, (size_t)p->width * bytes_per_px, (size_t)ww * bytes_per_px, wh, kind);
+  };
   if ((rc = s->fb.ensure(npix * 4)) != RT_OK) return rc;
-  // the caller's fill survives on miss pixels (image_buffer.rs:27-37): start from its content
-  HIP_TRY(hipMemcpy(s->fb.p, argb, npix * 4, hipMemcpyHostToDevice));
+  HIP_TRY(copy_window(s->fb.p, argb, 4, hipMemcpyHostToDevice));
   rt_aux ad{};
   if (aux) {
     if (aux->rgb) {
       if ((rc = s->aux_rgb.ensure(npix * 12)) != RT_OK) return rc;
-      HIP_TRY(hipMemcpy(s->aux_rgb.p, aux->rgb, npix * 12, hipMemcpyHostToDevice));
+      HIP_TRY(copy_window(s->aux_rgb.p, aux->rgb, 12, hipMemcpyHostToDevice));
       ad.rgb = (float*)s->aux_rgb.p;
     }
     if (aux->hit_id) {
       if ((rc = s->aux_id.ensure(npix * 4)) != RT_OK) return rc;
-      HIP_TRY(hipMemcpy(s->aux_id.p, aux->hit_id, npix * 4, hipMemcpyHostToDevice));
+      HIP_TRY(copy_window(s->aux_id.p, aux->hit_id, 4, hipMemcpyHostToDevice));
       ad.hit_id = (int32_t*)s->aux_id.p;
     }
     if (aux->hit_t) {
       if ((rc = s->aux_t.ensure(npix * 4)) != RT_OK) return rc;
-      HIP_TRY(hipMemcpy(s->aux_t.p, aux->hit_t, npix * 4, hipMemcpyHostToDevice));
+      HIP_TRY(copy_window(s->aux_t.p, aux->hit_t, 4, hipMemcpyHostToDevice));
       ad.hit_t = (float*)s->aux_t.p;
     }
   }
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EventPair ev;
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
   RtDevParams P;
   if ((rc = prepare(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P)) != RT_OK) return rc;
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  if ((rc = render_frame(s, P, nullptr)) != RT_OK) return rc;
-  HIP_TRY(hipEventRecord(e1, nullptr));
-  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventRecord(ev.e0, nullptr));
+  if ((rc = render_frame(s, P, nullptr, p->tuning.chunk_log2)) != RT_OK) return rc;
+  HIP_TRY(hipEventRecord(ev.e1, nullptr));
+  HIP_TRY(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  HIP_TRY(hipMemcpy(argb, s->fb.p, npix * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  auto t_copy = std::chrono::steady_clock::now();
+  HIP_TRY(copy_window(argb, s->fb.p, 4, hipMemcpyDeviceToHost));
+  const double d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
   if (aux) {
-    if (aux->rgb) HIP_TRY(hipMemcpy(aux->rgb, s->aux_rgb.p, npix * 12, hipMemcpyDeviceToHost));
-    if (aux->hit_id) HIP_TRY(hipMemcpy(aux->hit_id, s->aux_id.p, npix * 4, hipMemcpyDeviceToHost));
-    if (aux->hit_t) HIP_TRY(hipMemcpy(aux->hit_t, s->aux_t.p, npix * 4, hipMemcpyDeviceToHost));
+    if (aux->rgb) HIP_TRY(copy_window(aux->rgb, s->aux_rgb.p, 12, hipMemcpyDeviceToHost));
+    if (aux->hit_id) HIP_TRY(copy_window(aux->hit_id, s->aux_id.p, 4, hipMemcpyDeviceToHost));
+    if (aux->hit_t) HIP_TRY(copy_window(aux->hit_t, s->aux_t.p, 4, hipMemcpyDeviceToHost));
   }
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     if ((rc = rt_render_collect_stats(s, stats)) != RT_OK) return rc;
     stats->kernel_ms = ms;
+    stats->d2h_ms = d2h_ms;
     stats->total_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }

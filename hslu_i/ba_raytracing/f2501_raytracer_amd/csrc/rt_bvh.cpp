@@ -44,12 +44,13 @@ struct Aabb {
 };
 
 constexpr int kBins = 16;
-// tunables (environment overrides are for experiments only: RT_BVH_MAX_LEAF, RT_BVH_TRI_COST)
-uint32_t kMaxLeaf = 4;
-float kTraversalCost = 1.0f;
-float kTriCost = 2.0f;
-int kSplitDepth = 0;       // early split clipping: at most 2^depth references per triangle (0 = off: measured slower)
-float kSplitGain = 0.8f;   // split only if area(left) + area(right) < gain * area(whole)
+// tunables of the build in progress on this thread (rt_bvh_tuning of the scene description; thread_local: scenes for
+// distinct GPUs may be created concurrently)
+thread_local uint32_t kMaxLeaf = 4;
+constexpr float kTraversalCost = 1.0f;
+thread_local float kTriCost = 2.0f;
+thread_local int kSplitDepth = 0;       // early split clipping: at most 2^depth references per triangle (0 = off: measured slower)
+thread_local float kSplitGain = 0.8f;   // split only if area(left) + area(right) < gain * area(whole)
 
 struct Builder {
   const std::vector<Aabb>& tb;      // per-triangle padded bounds
@@ -259,11 +260,12 @@ void split_refs(const float (*poly)[3], int n, const Aabb& bounds, uint32_t tri,
 
 }  // namespace
 
-void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n, RtBvh* out) {
-  if (const char* e = getenv("RT_BVH_MAX_LEAF")) kMaxLeaf = (uint32_t)atoi(e) < 1 ? 1u : (uint32_t)atoi(e);
-  if (const char* e = getenv("RT_BVH_TRI_COST")) kTriCost = (float)atof(e);
-  if (const char* e = getenv("RT_BVH_SPLIT_DEPTH")) kSplitDepth = atoi(e);
-  if (const char* e = getenv("RT_BVH_SPLIT_GAIN")) kSplitGain = (float)atof(e);
+void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n,
+                  const rt_bvh_tuning& tuning, RtBvh* out) {
+  kMaxLeaf = tuning.max_leaf ? (tuning.max_leaf > 64u ? 64u : tuning.max_leaf) : 4u;
+  kTriCost = tuning.tri_cost > 0.f ? tuning.tri_cost : 2.0f;
+  kSplitDepth = tuning.split_depth > 8u ? 8 : (int)tuning.split_depth;
+  kSplitGain = tuning.split_gain > 0.f ? tuning.split_gain : 0.8f;
   out->nodes.clear();
   out->tri_order.clear();
   out->n_leaves = out->max_depth = out->max_leaf = 0;

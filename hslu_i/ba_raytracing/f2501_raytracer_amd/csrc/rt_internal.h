@@ -49,7 +49,8 @@ struct RtBvh {
 
 // Builds a binned-SAH BVH2 over the triangles (v1, e1, e2 as in rt_scene_desc).  Boxes are padded
 // so that the fp32 slab test can never cull a triangle the literal intersection test accepts.
-void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n, RtBvh* out);
+void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8_t* no_split, uint32_t n,
+                  const rt_bvh_tuning& tuning, RtBvh* out);
 
 // ---- kernel argument block ---------------------------------------------------------------------
 struct RtDevScene {
@@ -76,8 +77,14 @@ struct RtDevParams {
   float focus[3];
   float fw, fh, fd, eps_distance, air_ior, ambient;
   uint32_t flags;
-  uint32_t aa_rays;          // 0 = no anti-aliasing (one centre ray)
-  const float* aa_offsets;   // device, [aa_rays][2]
+  uint32_t aa_rays;          // samples per pixel the reference casts; 0 = no anti-aliasing (one centre ray)
+  // Bit-identical repeats of a sample offset are traced once (host: prepare()): aa_unique distinct offsets, thread u
+  // of a pixel traces aa_offsets[u] with weight aa_mult[u]; sample q of the reference's sum is thread aa_src[q].
+  uint32_t aa_unique;        // threads per pixel (== aa_rays when nothing repeats; 1 without anti-aliasing)
+  uint32_t weighted;         // 1: some ray carries a multiplicity > 1 (counters need per-lane sums)
+  const float* aa_offsets;   // device, [aa_unique][2]
+  const uint32_t* aa_mult;   // device, [aa_unique]
+  const uint32_t* aa_src;    // device, [aa_rays]
   uint32_t light_mult, cloud_seed, n_cloud_sets;
   // host-computed constants of the soft-shadow beam tests (uniform float arithmetic would sit in VGPRs):
   // delta = cloud_delta + 2 eps, delta + 1e-5, 0.998 eps, (1.3e-7 + 2.5e-6) eps, 1.01 eps + 2 * that, 1.98 eps
@@ -112,7 +119,9 @@ struct RtDevParams {
   // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;
   // nullptr = all super-tiles of the window
   const uint32_t* sup_list;
-  uint32_t n_sup;
+  uint32_t n_sup;         // number of super-tiles to render (listed, or all of the window)
+  // Morton key of a secondary hit point: q = (p - morton_lo) * morton_scale in [0, 1024)^3 (scene AABB, host)
+  float morton_lo[3], morton_scale[3];
   // secondary rays: trace -> sort by hit point -> shade (per queue chunk, indices relative to q_in_first)
   float* tr_t;            // [chunk] hit distance
   int32_t* tr_id;         // [chunk] canonical hit id, -1 miss

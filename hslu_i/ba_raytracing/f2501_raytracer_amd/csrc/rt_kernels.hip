@@ -37,7 +37,6 @@
 // v_rcp/v_rsq (1 ulp) and exp2/log2-based tanh/pow.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "rt_internal.h"
@@ -1038,13 +1037,13 @@ enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
 
 struct Wave {
   WaveCtx ctx;
-  uint32_t cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes;
+  uint32_t cnt_kind[3], cnt_shadow, cnt_pass, cnt_lanes, cnt_traced;
 };
 
 __device__ __forceinline__ void wave_init(Wave& w) {
   w.ctx.n_nodes = w.ctx.n_tris = w.ctx.s_nodes = w.ctx.s_tris = w.ctx.s_passes = w.ctx.n_exact = w.ctx.s_exact = 0;
   w.cnt_kind[0] = w.cnt_kind[1] = w.cnt_kind[2] = 0;
-  w.cnt_shadow = w.cnt_pass = w.cnt_lanes = 0;
+  w.cnt_shadow = w.cnt_pass = w.cnt_lanes = w.cnt_traced = 0;
 #if RT_PROFILE
   for (int i = 0; i < 7; i++) w.ctx.prof[i] = 0;
   w.ctx.t_mark = 0;
@@ -1054,7 +1053,7 @@ __device__ __forceinline__ void wave_init(Wave& w) {
 // Statistics: the wavefronts of a workgroup add their counters in LDS, then 14 threads issue one global
 // atomic each (RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
 // critical path; the host sums them).  Every thread of the workgroup must call this (two barriers).
-#define RT_N_COUNTERS 14u
+#define RT_N_COUNTERS 15u
 __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, unsigned long long written,
                                            unsigned long long* lds_cnt) {
   if (!P.counters) return;  // wave-uniform (kernel argument)
@@ -1064,11 +1063,11 @@ __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, 
 #if RT_PROFILE
     const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
                                                  w.cnt_pass,    w.ctx.prof[6], w.ctx.prof[0],  w.ctx.prof[1], w.ctx.prof[2],
-                                                 w.ctx.prof[3], w.ctx.s_passes, w.ctx.prof[4], w.ctx.prof[5]};
+                                                 w.ctx.prof[3], w.ctx.s_passes, w.ctx.prof[4], w.ctx.prof[5], w.cnt_traced};
 #else
     const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
                                                  w.cnt_pass,    w.cnt_lanes,   w.ctx.n_nodes,  w.ctx.n_tris, w.ctx.s_nodes,
-                                                 w.ctx.s_tris,  w.ctx.s_passes, w.ctx.n_exact, w.ctx.s_exact};
+                                                 w.ctx.s_tris,  w.ctx.s_passes, w.ctx.n_exact, w.ctx.s_exact, w.cnt_traced};
 #endif
 #pragma unroll
     for (unsigned i = 0; i < RT_N_COUNTERS; i++)
@@ -1089,18 +1088,37 @@ struct RayIn {
   int depth;      // Option<usize>: -1 = None
   int kind;
   uint32_t pix;
+  uint32_t mult;  // how many identical rays of the reference this one stands for (repeated AA samples)
 };
+
+// depth (-1 = None .. 64), kind and multiplicity of a ray in one dword (queue plane 1 .w, LDS stash)
+__device__ __forceinline__ int pack_dkm(int depth, int kind, uint32_t mult) {
+  return (int)((mult << 10) | ((uint32_t)(depth + 1) << 2) | (uint32_t)kind);
+}
+__device__ __forceinline__ void unpack_dkm(int v, int& depth, int& kind, uint32_t& mult) {
+  kind = v & 3;
+  depth = (int)(((uint32_t)v >> 2) & 0xFFu) - 1;
+  mult = (uint32_t)v >> 10;
+}
+
+// sum of a per-lane value over the wavefront (uniform result)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) v += (uint32_t)__shfl_xor((int)v, k, 64);
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
 struct RayOut {
   bool hit;
   float t;
   int id;
   V3 contrib;  // Wt * own terms of this node (zero on miss)
+  uint32_t pix, mult;  // of the ray (valid when hit; read back from the LDS stash)
 };
 
 // appends the lanes with `on` to the ray queue (wave-level compaction: one atomic per wavefront)
 __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, V3 d, float n_start, V3 Wt,
-                                           int depth, int kind, uint32_t pix) {
+                                           int depth, int kind, uint32_t pix, uint32_t mult) {
   unsigned long long m = wave_ballot(on);
   if (!m) return;
   uint32_t n = (uint32_t)__popcll(m);
@@ -1112,7 +1130,7 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
     uint32_t i = base + rankl;
     if (i < P.q_capacity) {
       P.q_out[0 * (size_t)P.q_capacity + i] = make_float4(o.x, o.y, o.z, n_start);
-      P.q_out[1 * (size_t)P.q_capacity + i] = make_float4(d.x, d.y, d.z, __int_as_float((depth << 2) | kind));
+      P.q_out[1 * (size_t)P.q_capacity + i] = make_float4(d.x, d.y, d.z, __int_as_float(pack_dkm(depth, kind, mult)));
       P.q_out[2 * (size_t)P.q_capacity + i] = make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix));
     } else {
       atomicAdd(P.q_overflow, 1u);  // host sizes batches so this cannot happen; reported as an error
@@ -1134,6 +1152,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   out.t = 0.0f;
   out.id = -1;
   out.contrib = mk(0.0f, 0.0f, 0.0f);
+  out.pix = 0;
+  out.mult = 1;
   WaveCtx& W = wv.ctx;
   const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
   const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
@@ -1146,10 +1166,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   if (!bal) return out;
   Hit h = pre;
   if (!PRE) {
-    // ray accounting: lanes entering cast_ray, by kind
-    wv.cnt_kind[0] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_PRIMARY));
-    wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
+    // ray accounting: lanes entering cast_ray (camera rays here; children are counted by rt_trace_kernel), each
+    // standing for `mult` rays of the reference
+    wv.cnt_kind[0] += P.weighted ? wave_sum(alive ? r.mult : 0u) : (uint32_t)__popcll(bal);
+    wv.cnt_traced += (uint32_t)__popcll(bal);
     WSTAT(wv.cnt_pass += 1);
     WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
     const unsigned long long t_n = PROF_T();
@@ -1181,7 +1201,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     st[2 * 256] = W0.z;
     st[3 * 256] = a0;
     st[4 * 256] = r.n_start;
-    st[5 * 256] = __int_as_float((r.depth << 2) | r.kind);
+    st[5 * 256] = __int_as_float(pack_dkm(r.depth, r.kind, r.mult));
     st[7 * 256] = h.t;
     st[8 * 256] = __int_as_float(out.id);
     st[9 * 256] = __uint_as_float(r.pix);
@@ -1215,7 +1235,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   }
   // every hit point casts lights x N shadow rays in the reference (raytracer.rs:24); counted here once, whatever
   // part of them the classifications below resolve without a traversal
-  wv.cnt_shadow += sc.n_lights * N * (uint32_t)__popcll(hit_m);
+  wv.cnt_shadow += sc.n_lights * N * (P.weighted ? wave_sum(hit ? r.mult : 0u) : (uint32_t)__popcll(hit_m));
   for (uint32_t l = 0; l < sc.n_lights; l++) {
     const float4 L0 = sload<float4>(sc, sc.off_lights + l * 32u);
     const float4 L1 = sload<float4>(sc, sc.off_lights + l * 32u + 16u);
@@ -1419,15 +1439,14 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     Wt = mk(st[0 * 256], st[1 * 256], st[2 * 256]);
     a = st[3 * 256];
     n_start = st[4 * 256];
-    int dk = __float_as_int(st[5 * 256]);
-    depth = dk >> 2;
-    kind = dk & 3;
+    unpack_dkm(__float_as_int(st[5 * 256]), depth, kind, out.mult);
     uint32_t mat_row = __float_as_uint(st[6 * 256]);
     RT_OPAQUE(mat_row);  // keeps hipcc from carrying the row's addresses through the loop (in scratch)
     m = load_mat(sc, mat_row);
     out.t = st[7 * 256];
     out.id = __float_as_int(st[8 * 256]);
     pixel = __float_as_uint(st[9 * 256]);
+    out.pix = pixel;
   }
   (void)kind;
   V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
@@ -1468,7 +1487,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         cW = Wt * Rf;
       }
     }
-    queue_push(P, spawn, co, cd, n_start, cW, cdepth, KIND_REFL, pixel);
+    queue_push(P, spawn, co, cd, n_start, cW, cdepth, KIND_REFL, pixel, out.mult);
   }
   // ---- calculate_refractions, :279-524 --------------------------------------------------------------
   {
@@ -1503,7 +1522,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         cior = n2;
       }
     }
-    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, pixel);
+    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, pixel, out.mult);
   }
   return out;
 }
@@ -1512,19 +1531,24 @@ __device__ __forceinline__ uint32_t pack_argb(V3 c) {
   return 0xFF000000u | (to_u8(c.x) << 16) | (to_u8(c.y) << 8) | to_u8(c.z);
 }
 
-__device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c) {
+// `mult` identical rays of the reference add `mult` identical fixed-point terms: exact in the integer domain
+__device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c, uint32_t mult) {
   long long* a = P.acc + 4 * (size_t)pix;
-  atomicAdd((unsigned long long*)&a[0], (unsigned long long)__float2ll_rn(c.x * RT_ACC_SCALE));
-  atomicAdd((unsigned long long*)&a[1], (unsigned long long)__float2ll_rn(c.y * RT_ACC_SCALE));
-  atomicAdd((unsigned long long*)&a[2], (unsigned long long)__float2ll_rn(c.z * RT_ACC_SCALE));
+  atomicAdd((unsigned long long*)&a[0], (unsigned long long)(__float2ll_rn(c.x * RT_ACC_SCALE) * (long long)mult));
+  atomicAdd((unsigned long long*)&a[1], (unsigned long long)(__float2ll_rn(c.y * RT_ACC_SCALE) * (long long)mult));
+  atomicAdd((unsigned long long*)&a[2], (unsigned long long)(__float2ll_rn(c.z * RT_ACC_SCALE) * (long long)mult));
 }
 
 // ------------------------------------------------------------------------------------------------
-// primary kernel: one thread per (pixel, AA sample).  A 256-thread workgroup owns
-// ppw = 256 / n_samples consecutive pixels in "tile order" (16x16 super-tiles of 4x4 tiles), so a
-// wavefront's 64 camera rays are the samples of a few adjacent pixels -- maximally coherent for the
-// wave-cooperative traversal.  Sample colours meet in LDS and are summed per pixel in the
-// reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
+// primary kernel: one thread per (pixel, DISTINCT AA sample).  The reference's sample table repeats itself
+// (raytracer_renderer.rs:107-122: [0,0], then [1,1]s; the 8 directions restart in every 8-lane chunk, :1111-1116):
+// 9 distinct origins among 16 samples, 9 among 24 with extreme_quality.  Repeats give bit-identical rays and
+// colours (the light cloud is chosen per pixel), so every distinct sample is traced once (n_thr threads per
+// pixel) and its colour is read n times by the per-pixel sum; its children carry the multiplicity.
+// A 256-thread workgroup owns ppw = 256 / n_thr consecutive pixels in "tile order" (16x16 super-tiles of
+// 4x4 tiles; a workgroup may straddle two super-tiles), so a wavefront's 64 camera rays are the samples of a
+// few adjacent pixels -- maximally coherent for the wave-cooperative traversal.  Sample colours meet in LDS and
+// are summed per pixel in the reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
 // ------------------------------------------------------------------------------------------------
 template <bool CULL>
 __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
@@ -1532,7 +1556,8 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   Wave wv;
   wave_init(wv);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
-  const uint32_t n_samples = aa ? P.aa_rays : 1u;
+  const uint32_t n_samples = aa ? P.aa_rays : 1u;  // samples of the reference's per-pixel sum
+  const uint32_t n_thr = aa ? P.aa_unique : 1u;    // threads per pixel (distinct samples)
   // thread -> (pixel, AA sample): workgroup -> 16x16 super-tile (through the list of super-tiles this rank
   // owns, if any) -> 4x4 tile -> pixel.  Evaluated twice (before the ray and again for the accumulation) so
   // that nothing of it has to survive the light loops in registers.
@@ -1542,16 +1567,16 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   };
   auto map_thread = [&](uint32_t tid) {
     PixelMap m;
-    const uint32_t ppw = 256u / n_samples;  // pixels per workgroup (host guarantees n_samples <= 256)
-    m.slot = tid / n_samples;
-    m.k = tid - m.slot * n_samples;
+    const uint32_t ppw = 256u / n_thr;  // pixels per workgroup (host guarantees n_thr <= 256)
+    m.slot = tid / n_thr;
+    m.k = tid - m.slot * n_thr;
     const uint32_t st_x = (P.win_w + 15u) / 16u;
-    const uint32_t wgs_per_sup = (256u + ppw - 1u) / ppw;
     const uint32_t wg = P.batch_first_wg + blockIdx.x;
-    const uint32_t sup_slot = wg / wgs_per_sup;
-    const uint32_t sup = P.sup_list ? uload(&P.sup_list[sup_slot]) : sup_slot;
-    const uint32_t in_sup = (wg - sup_slot * wgs_per_sup) * ppw + m.slot;
-    const bool lane_used = (m.slot < ppw) && (in_sup < 256u);
+    const uint32_t g = wg * ppw + m.slot;  // pixel ordinal in super-tile order
+    const uint32_t sup_slot = g >> 8, in_sup = g & 255u;
+    const bool lane_used = (m.slot < ppw) && (sup_slot < P.n_sup);
+    uint32_t sup = sup_slot;
+    if (P.sup_list) sup = lane_used ? P.sup_list[sup_slot] : 0u;
     const uint32_t t4 = (in_sup >> 4) & 15u, p4 = in_sup & 15u;
     const uint32_t lx = (sup % st_x) * 16u + (t4 & 3u) * 4u + (p4 & 3u);
     const uint32_t ly = (sup / st_x) * 16u + (t4 >> 2) * 4u + (p4 >> 2);
@@ -1580,6 +1605,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   r.depth = -1;
   r.kind = KIND_PRIMARY;
   r.pix = pm.pix;
+  r.mult = (P.weighted && pix_on) ? P.aa_mult[k] : 1u;
 
   Hit none;
   none.t = INFINITY;
@@ -1600,7 +1626,9 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   __syncthreads();
   bool wrote = false;
   if (pm2.k == 0 && pm2.on) {
-    const float4* s = lds_rgbh + slot * n_samples;
+    const float4* s = lds_rgbh + slot * n_thr;
+    // sample q of the reference's sum -> the thread that traced it (wave-uniform q: scalar load)
+    auto src = [&](uint32_t q) { return P.weighted ? uload(&P.aa_src[q]) : q; };
     V3 color;
     bool any = false;
     if (!aa) {
@@ -1612,18 +1640,24 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       for (int l = 0; l < 8; l++) first[l] = rest[l] = mk(0, 0, 0);
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        if ((uint32_t)l < n_samples && s[l].w != 0.0f) {
-          first[l] = mk(s[l].x, s[l].y, s[l].z);
-          any = true;
+        if ((uint32_t)l < n_samples) {
+          const float4 c = s[src((uint32_t)l)];
+          if (c.w != 0.0f) {
+            first[l] = mk(c.x, c.y, c.z);
+            any = true;
+          }
         }
       }
       for (uint32_t base = 8; base < n_samples; base += 8) {
 #pragma unroll
         for (int l = 0; l < 8; l++) {
           uint32_t q = base + (uint32_t)l;
-          if (q < n_samples && s[q].w != 0.0f) {
-            rest[l] = mk(s[q].x, s[q].y, s[q].z) + rest[l];
-            any = true;
+          if (q < n_samples) {
+            const float4 c = s[src(q)];
+            if (c.w != 0.0f) {
+              rest[l] = mk(c.x, c.y, c.z) + rest[l];
+              any = true;
+            }
           }
         }
       }
@@ -1636,7 +1670,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       wrote = true;
       if (P.acc) {
         // secondary rays are streaming: the pixel is resolved by rt_resolve_kernel
-        acc_add(P, pix, color);
+        acc_add(P, pix, color, 1u);
         P.acc[4 * (size_t)pix + 3] = 1;
       } else {
         P.argb[pix] = pack_argb(color);
@@ -1686,9 +1720,7 @@ __device__ __forceinline__ RayIn load_queued_ray(const RtDevParams& P, size_t j)
   r.o = mk(a.x, a.y, a.z);
   r.n_start = a.w;
   r.d_raw = mk(b.x, b.y, b.z);
-  int dk = __float_as_int(b.w);
-  r.depth = dk >> 2;
-  r.kind = dk & 3;
+  unpack_dkm(__float_as_int(b.w), r.depth, r.kind, r.mult);
   r.Wt = mk(c.x, c.y, c.z);
   r.pix = __float_as_uint(c.w);
   return r;
@@ -1702,6 +1734,7 @@ __device__ __forceinline__ RayIn idle_ray() {
   r.depth = 1;
   r.kind = KIND_REFL;
   r.pix = 0;
+  r.mult = 1;
   return r;
 }
 __device__ __forceinline__ uint32_t morton_expand10(uint32_t v) {
@@ -1727,8 +1760,14 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
   h.t = INFINITY;
   h.id = -1;
   if (bal) {
-    wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
-    wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
+    if (P.weighted) {
+      wv.cnt_kind[1] += wave_sum((alive && r.kind == KIND_REFL) ? r.mult : 0u);
+      wv.cnt_kind[2] += wave_sum((alive && r.kind == KIND_REFR) ? r.mult : 0u);
+    } else {
+      wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
+      wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
+    }
+    wv.cnt_traced += (uint32_t)__popcll(bal);
     WSTAT(wv.cnt_pass += 1);
     WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
     h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
@@ -1738,10 +1777,10 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
     uint32_t key = 0xFFFFFFFFu;
     if (hit) {
       V3 p = fma_s(d, h.t, r.o);
-      // scene units are ~[0,1]; [-0.5, 1.5) x [-0.5, 1.5) x [-0.5, 2.0) covers both named scenes generously
-      uint32_t qx = (uint32_t)clampf((p.x + 0.5f) * 512.0f, 0.0f, 1023.0f);
-      uint32_t qy = (uint32_t)clampf((p.y + 0.5f) * 512.0f, 0.0f, 1023.0f);
-      uint32_t qz = (uint32_t)clampf((p.z + 0.5f) * 409.6f, 0.0f, 1023.0f);
+      // 10 bits per axis over the scene's bounding box (host: prepare())
+      uint32_t qx = (uint32_t)clampf((p.x - P.morton_lo[0]) * P.morton_scale[0], 0.0f, 1023.0f);
+      uint32_t qy = (uint32_t)clampf((p.y - P.morton_lo[1]) * P.morton_scale[1], 0.0f, 1023.0f);
+      uint32_t qz = (uint32_t)clampf((p.z - P.morton_lo[2]) * P.morton_scale[2], 0.0f, 1023.0f);
       key = morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2);
     }
     P.tr_t[i] = h.t;
@@ -1779,7 +1818,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
     if (have) r = load_queued_ray(P, (size_t)P.q_in_first + j);
   }
   RayOut out = process_ray<CULL, true>(sc, P, wv, have, r, lds_stash, h);
-  if (out.hit) acc_add(P, r.pix, out.contrib);
+  if (out.hit) acc_add(P, out.pix, out.contrib, out.mult);
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
@@ -1822,30 +1861,18 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
 // ---- host-side launchers ---------------------------------------------------------------------------
 uint32_t rt_primary_pixels_per_wg(const RtDevParams& p) {
   const bool aa = (p.flags & RT_FLAG_ANTI_ALIASING) && p.aa_rays > 0;
-  return 256u / (aa ? p.aa_rays : 1u);
+  return 256u / (aa ? p.aa_unique : 1u);
 }
 
-// workgroups of the primary kernel: every (listed) 16x16 super-tile takes ceil(256 / ppw) of them
+// workgroups of the primary kernel: the 256 pixels of every (listed) 16x16 super-tile, ppw per workgroup
 uint32_t rt_primary_total_wgs(const RtDevParams& p) {
-  uint32_t st_x = (p.win_w + 15u) / 16u, st_y = (p.win_h + 15u) / 16u;
-  uint32_t n_sup = p.sup_list ? p.n_sup : st_x * st_y;
   uint32_t ppw = rt_primary_pixels_per_wg(p);
-  return n_sup * ((256u + ppw - 1u) / ppw);
-}
-
-// experiments only: RT_DEBUG_LDS_PAD=<bytes> adds unused dynamic LDS to throttle occupancy
-static unsigned debug_lds_pad() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("RT_DEBUG_LDS_PAD");
-    v = e ? atoi(e) : 0;
-  }
-  return (unsigned)v;
+  return (uint32_t)(((uint64_t)p.n_sup * 256u + ppw - 1u) / ppw);
 }
 
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;  // nothing owned inside the window
-  hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), debug_lds_pad(), (hipStream_t)stream, sc, p);
+  hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 

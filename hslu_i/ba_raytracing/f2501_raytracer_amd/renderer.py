@@ -47,9 +47,9 @@ class ImageBuffer:
 class DeviceScene:
     """Owns an `rt_scene*` (device copies + BVH)."""
 
-    def __init__(self, flat: FlatScene, device: int = 0):
+    def __init__(self, flat: FlatScene, device: int = 0, bvh: Optional[Dict] = None):
         lib = _lib.load()
-        desc, keep = _abi.make_scene_desc(flat)
+        desc, keep = _abi.make_scene_desc(flat, bvh)
         h = C.c_void_p()
         _lib.check(lib.rt_scene_create(C.byref(desc), int(device), C.byref(h)))
         self._h = h
@@ -90,7 +90,7 @@ class RaytracerRenderer:
         self.cfg = cfg
         self.device = int(device)
         self.traversal = int(traversal)
-        self._cache: Optional[Tuple[int, DeviceScene]] = None
+        self._cache: Optional[Tuple[bytes, DeviceScene]] = None
         self.last_stats: Optional[Dict] = None
 
     @staticmethod
@@ -98,24 +98,30 @@ class RaytracerRenderer:
         return RaytracerRenderer(cfg if cfg is not None else RenderConfig.from_features(()))
 
     def device_scene(self, scene) -> DeviceScene:
+        """The reference's `render(&buffer, &scene)` reads the scene on every call; so does this: the scene is
+        flattened and fingerprinted each time, and the cached device copy (+ BVH) is reused only when the content
+        is unchanged.  Pass a `DeviceScene` to skip both."""
         if isinstance(scene, DeviceScene):
             return scene
-        key = id(scene)
+        flat = scene.flatten() if isinstance(scene, Scene) else scene
+        key = flat.fingerprint()
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
-        flat = scene.flatten() if isinstance(scene, Scene) else scene
+        if self._cache is not None:
+            self._cache[1].close()
         ds = DeviceScene(flat, self.device)
         self._cache = (key, ds)
         return ds
 
     def render(self, buffer: ImageBuffer, scene, window=None, n_ranks: int = 1, rank: int = 0,
-               aux: bool = False):
-        """Renders `scene` into `buffer` (hit pixels only).  Returns aux planes when aux=True."""
+               aux: bool = False, tuning: Optional[Dict] = None):
+        """Renders `scene` into `buffer` (hit pixels only).  Returns aux planes when aux=True.
+        tuning: rt_tuning fields (execution knobs that never change the image)."""
         cfg = self.cfg
         if buffer.width != cfg.width or buffer.height != cfg.height:
             raise ValueError(f"buffer is {buffer.width}x{buffer.height}, config renders {cfg.width}x{cfg.height}")
         ds = self.device_scene(scene)
-        p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank, traversal=self.traversal)
+        p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank, traversal=self.traversal, tuning=tuning)
         st = _abi.rt_stats()
         a = _abi.rt_aux()
         planes = None

@@ -379,6 +379,21 @@ class FlatScene:
         return FlatScene(self.sphere_center, self.sphere_r_sq, self.sphere_r_inv, self.sphere_material,
                          z3, z3, z3, z3, np.zeros((0,), np.uint32), self.materials, self.lights)
 
+    def fingerprint(self) -> bytes:
+        """Content hash of every array (the renderer's device-scene cache key: a mutated or different scene must
+        never render with a stale device copy)."""
+        import hashlib
+
+        h = hashlib.blake2b(digest_size=16)
+        c = self.contiguous()
+        for name in ("sphere_center", "sphere_r_sq", "sphere_r_inv", "sphere_material", "tri_v1", "tri_e1", "tri_e2",
+                     "tri_normal", "tri_material", "materials", "lights"):
+            a = getattr(c, name)
+            h.update(name.encode())
+            h.update(str(a.shape).encode())
+            h.update(a.tobytes())
+        return h.digest()
+
     def contiguous(self) -> "FlatScene":
         f = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
         return FlatScene(

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 /* ---- error codes -------------------------------------------------------------------------- */
 #define RT_OK 0
@@ -72,6 +72,14 @@ extern "C" {
  * the one PointLight::new stores, i.e. ALREADY passed through maximize_value (light.rs:175-181). */
 #define RT_LIGHT_STRIDE 7u
 
+/* BVH builder knobs (no reference counterpart: the reference has no acceleration structure).  0 = default. */
+typedef struct rt_bvh_tuning {
+  uint32_t max_leaf;    /* triangles per leaf, default 4 */
+  float tri_cost;       /* SAH cost of one triangle test relative to one node visit, default 2 */
+  uint32_t split_depth; /* early split clipping: at most 2^depth references per triangle, default 0 = off */
+  float split_gain;     /* split only if area(left) + area(right) < gain * area(whole), default 0.8 */
+} rt_bvh_tuning;
+
 typedef struct rt_scene_desc {
   uint32_t abi_version; /* RT_ABI_VERSION */
 
@@ -93,7 +101,21 @@ typedef struct rt_scene_desc {
 
   uint32_t n_lights;
   const float* lights; /* [n_lights][RT_LIGHT_STRIDE]: x,y,z, r,g,b, intensity */
+
+  rt_bvh_tuning bvh; /* all 0 = defaults */
 } rt_scene_desc;
+
+/* Execution knobs that never change the image (no reference counterpart).  All 0 = defaults. */
+#define RT_CAND_CAP_NONE 0xFFFFFFFFu
+typedef struct rt_tuning {
+  /* Soft shadows share one BVH walk per (wavefront, light): the walk collects at most this many candidate
+   * triangles (1..64; 0 = default 64).  RT_CAND_CAP_NONE: no sharing, one BVH walk per shadow sample. */
+  uint32_t shadow_candidate_cap;
+  uint32_t chunk_log2;  /* log2 of the rays per secondary launch / primary batch; 0 = sized from free HBM */
+  uint32_t no_aa_dedup; /* 1: trace every AA sample, also the bit-identical repeats of the sample table */
+  uint32_t no_counters; /* 1: skip the ray counters of rt_stats (timing experiments) */
+  uint32_t reserved[4];
+} rt_tuning;
 
 typedef struct rt_params {
   uint32_t abi_version; /* RT_ABI_VERSION */
@@ -141,6 +163,8 @@ typedef struct rt_params {
   uint32_t rank;
 
   uint32_t traversal; /* RT_TRAVERSAL_* */
+
+  rt_tuning tuning; /* all 0 = defaults */
 } rt_params;
 
 /* optional per-pixel debug planes for parity checks (all nullable, caller-owned, W*H each) */
@@ -156,8 +180,14 @@ typedef struct rt_stats {
   uint64_t rays_refraction; /* ... as refraction children (raytracer_renderer.rs:493) */
   uint64_t rays_shadow;     /* has_any_intersection calls, raytracer.rs:24 */
   uint64_t pixels_written;
+  /* Rays actually traced on the GPU (nearest-hit searches).  rays_primary/reflection/refraction/shadow count what
+   * the reference casts; AA samples whose origin offsets are bit-identical repeats of another sample (7 of 16 with
+   * the deterministic table, 15 of 24 with extreme_quality: raytracer_renderer.rs:107-122,1111-1116) are traced once
+   * and weighted by their multiplicity, so rays_traced <= the sum of the three.  CPU oracle: equal to the sum. */
+  uint64_t rays_traced;
   double kernel_ms; /* device time of the render kernel(s) (CPU oracle: wall time) */
   double total_ms;  /* wall time of the call incl. copies */
+  double d2h_ms;    /* rt_render / rt_render_multi: wall time of the device -> host copy of the packed pixels */
   /* The wave_* work statistics below are filled only by the statistics build of the library
    * (`make STATS=1` -> librt_hip_stats.so, used by tools/perf_ab.py); the shipped kernels leave them 0.
    * GPU only (0 from the CPU oracle): SIMD efficiency of the ray loop.  wave_ray_passes = number of

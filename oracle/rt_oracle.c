@@ -684,6 +684,7 @@ int rt_cpu_render(const rt_scene_desc* desc, const rt_params* params, uint32_t* 
       stats->rays_shadow += jobs[i].shadow;
       stats->pixels_written += jobs[i].written;
     }
+    stats->rays_traced = stats->rays_primary + stats->rays_reflection + stats->rays_refraction;
     stats->kernel_ms = t1 - t0;
     stats->total_ms = t1 - t0;
   }

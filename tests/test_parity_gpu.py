@@ -4,6 +4,8 @@ Bars: hit ids and pixel indices bit-exact; hit distance bit-exact (same fp32 op 
 rounded div/sqrt on both sides); un-quantised RGB within 1e-4 (BASELINE.json north_star); packed
 pixels may differ by 1 LSB where tanhf/powf differ in the last ulp.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -26,10 +28,12 @@ def window_mask(cfg, win):
     return m.ravel()
 
 
-def gpu_render(cfg, flat, win=None, traversal=_abi.RT_TRAVERSAL_BVH, n_ranks=1, rank=0):
+def gpu_render(cfg, flat, win=None, traversal=_abi.RT_TRAVERSAL_BVH, n_ranks=1, rank=0, aux=True, **tuning):
+    """One render through the C ABI.  tuning: rt_tuning fields -- shadow_candidate_cap (shared soft-shadow candidate
+    cap; RT_CAND_CAP_NONE = a BVH walk per sample), chunk_log2 (rays per secondary launch), no_aa_dedup."""
     buf = ImageBuffer.new(cfg.width, cfg.height)
     r = RaytracerRenderer(cfg, device=0, traversal=traversal)
-    planes = r.render(buf, flat, window=win, aux=True, n_ranks=n_ranks, rank=rank)
+    planes = r.render(buf, flat, window=win, aux=aux, n_ranks=n_ranks, rank=rank, tuning=tuning)
     return buf.buffer.copy(), planes, r.last_stats
 
 
@@ -224,17 +228,16 @@ def test_tiny_triangle_counts_single_leaf_bvh(n_tris):
     compare(cfg, flat, None)
 
 
-def test_candidate_overflow_falls_back_to_per_sample_walk(monkeypatch):
+def test_candidate_overflow_falls_back_to_per_sample_walk():
     """Soft shadows share one BVH walk per (wavefront, light); when the candidate list overflows the
-    kernel must fall back to a walk per sample with identical results.  RT_CAND_MAX (experiment knob
-    of the library) forces the overflow."""
+    kernel must fall back to a walk per sample with identical results.  rt_tuning.shadow_candidate_cap forces
+    the overflow."""
     cfg = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"], n_cloud_sets=64)
     flat = scenes.semesterbild(cfg, "text_lowres").flatten()
     win = (420, 330, 64, 48)
     a_ref, p_ref, s_ref = gpu_render(cfg, flat, win)
-    for cap in ("0", "3"):
-        monkeypatch.setenv("RT_CAND_MAX", cap)
-        a, p, s_ = gpu_render(cfg, flat, win)
+    for cap in (_abi.RT_CAND_CAP_NONE, 3):
+        a, p, s_ = gpu_render(cfg, flat, win, shadow_candidate_cap=cap)
         # every occlusion decision is identical; the colour differs only by the rounding of the fast
         # arrival path (sets with nothing to test skip the IEEE normalisation of the light direction)
         assert np.array_equal(p["hit_id"], p_ref["hit_id"]) and np.array_equal(p["hit_t"], p_ref["hit_t"])
@@ -242,7 +245,6 @@ def test_candidate_overflow_falls_back_to_per_sample_walk(monkeypatch):
         ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
         assert np.abs(ch(a) - ch(a_ref)).max() <= 1
         assert s_["rays_shadow"] == s_ref["rays_shadow"]
-    monkeypatch.delenv("RT_CAND_MAX")
 
 
 def test_extreme_quality_24_samples_ragged_workgroups():
@@ -387,7 +389,7 @@ def test_umbra_penumbra_and_horizon_classification():
     compare(cfg, flat, (30, 70, 140, 60))
 
 
-def test_config3_full_size_properties(monkeypatch):
+def test_config3_full_size_properties():
     """BASELINE.json configs[2] at its full size (1620x1350, 16 rays/px, 5 x 10 shadow rays per hit, text.obj):
     size-independent properties instead of the (hours-long) brute-force oracle --
     determinism, the multi-GPU tile partition, and the whole soft-shadow machinery (shared candidate lists, beam
@@ -406,11 +408,20 @@ def test_config3_full_size_properties(monkeypatch):
         assert not (acc[ar != 0] != 0).any(), "tiles of two ranks overlap"
         acc |= ar
     assert np.array_equal(acc, a0), "union of the ranks' tiles differs from the single-GPU frame"
-    monkeypatch.setenv("RT_CAND_MAX", "0")  # every (wavefront, light) overflows: one BVH walk per sample, no shortcuts
-    a2, p2, s2 = gpu_render(cfg, flat)
-    monkeypatch.delenv("RT_CAND_MAX")
+    # no candidate sharing: one BVH walk per sample, none of the beam-level shortcuts
+    a2, p2, s2 = gpu_render(cfg, flat, shadow_candidate_cap=_abi.RT_CAND_CAP_NONE)
     assert np.array_equal(p2["hit_id"], p0["hit_id"]) and np.array_equal(p2["hit_t"], p0["hit_t"])
     assert s2["rays_shadow"] == s0["rays_shadow"]
+    # The sample table repeats itself (9 distinct origins among 16).  Tracing every repeat takes the same decisions;
+    # the colour may move by the rounding of the arrival fast path (a repeat sits in another wavefront, and whether
+    # a (wavefront, light) set has "nothing to test" is a wavefront-level classification).
+    a4, p4, s4 = gpu_render(cfg, flat, no_aa_dedup=1)
+    assert np.array_equal(p4["hit_id"], p0["hit_id"]) and np.array_equal(p4["hit_t"], p0["hit_t"])
+    assert np.abs(p4["rgb"] - p0["rgb"]).max() <= 2e-6
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    assert np.abs(ch(a4) - ch(a0)).max() <= 1
+    assert all(s4[k] == s0[k] for k in ("rays_primary", "rays_shadow", "pixels_written"))
+    assert s4["rays_traced"] == s4["rays_primary"] and s0["rays_traced"] * 16 == s0["rays_primary"] * 9
     d = np.abs(p2["rgb"] - p0["rgb"]).max()
     assert d <= 2e-6, d
     ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
@@ -432,17 +443,180 @@ def test_progressive_bands_equal_one_render():
     assert np.array_equal(buf.buffer, full)
 
 
-def test_ray_streaming_with_tiny_chunks(monkeypatch):
+def test_ray_streaming_with_tiny_chunks():
     """Forces many primary batches and multi-chunk queue levels (RT_CHUNK_LOG2 = 10 -> 1024 rays per
     launch): the deepest-first drain and the queue-capacity invariant must give the same image."""
     cfg = RenderConfig.from_features(["realistic", "anti_aliasing"], depth_override=5)
     flat = scenes.test_scene(cfg).flatten()
     win = (300, 200, 96, 64)
     a_ref, p_ref, s_ref = gpu_render(cfg, flat, win)
-    monkeypatch.setenv("RT_CHUNK_LOG2", "10")
-    a, p, s_ = gpu_render(cfg, flat, win)
-    monkeypatch.delenv("RT_CHUNK_LOG2")
+    a, p, s_ = gpu_render(cfg, flat, win, chunk_log2=10)
     assert np.array_equal(a, a_ref) and np.array_equal(p["rgb"], p_ref["rgb"])
     for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow"):
         assert s_[k] == s_ref[k]
     compare(cfg, flat, win)
+
+
+# ---- every BASELINE.json config at its stated workload (bench.build_workload is what bench.py times) ----------
+import bench  # noqa: E402
+
+
+def test_config3_text_obj_windows_vs_oracle():
+    """BASELINE configs[2] exactly as bench.py builds it (semesterbild, text.obj = 14 521 mesh triangles, 1620x1350,
+    16 rays/px, 5 x 10 shadow rays per hit, 1024 cloud sets): windows on the text, through the glass sphere's rim
+    and across a text/wall silhouette, against the brute-force oracle."""
+    cfg, flat, _ = bench.build_workload("c3")
+    assert flat.n_triangles >= 14521 and cfg.aa_total_rays == 16 and cfg.point_light_multiplicator == 10
+    for win in ((400, 380, 24, 16), (548, 418, 24, 16), (1120, 600, 24, 16), (330, 700, 24, 16)):
+        compare(cfg, flat, win)
+
+
+def test_config4_at_spec_windows_vs_oracle():
+    """BASELINE configs[3] exactly as bench.py builds it: high_resolution + realistic + extreme_quality (24 rays/px,
+    28-light clouds = 140 shadow rays per hit), recursion depth 8, text.obj.  Windows: the glass sphere's rim with
+    the text behind it, the text outside the sphere, and the pile of metallic-glass spheres (deep ray trees)."""
+    cfg, flat, _ = bench.build_workload("c4")
+    assert (cfg.width, cfg.height) == (1620, 1350) and cfg.aa_total_rays == 24 and cfg.point_light_multiplicator == 28
+    assert cfg.max_depth_reflection == 8 and cfg.max_depth_refraction == 8 and flat.n_triangles >= 14521
+    for win in ((556, 418, 12, 8), (400, 380, 12, 8), (1246, 990, 4, 3)):
+        compare(cfg, flat, win)
+
+
+def test_config5_at_spec_windows_vs_oracle():
+    """BASELINE configs[4]: as config 4 at 3840x2160 (the scene itself changes with the aspect ratio, lib.rs:73-92)."""
+    cfg, flat, _ = bench.build_workload("c5")
+    assert (cfg.width, cfg.height) == (3840, 2160) and cfg.aa_total_rays == 24 and cfg.point_light_multiplicator == 28
+    for win in ((1300, 700, 12, 8), (902, 623, 12, 8), (2958, 1584, 4, 3)):
+        compare(cfg, flat, win)
+
+
+def _full_size_properties(key):
+    """Size-independent properties of a full frame of a streaming (reflections + refractions) config: determinism, the
+    3-rank tile partition, the soft-shadow machinery against the plain per-sample BVH walk (cand_cap = 0), invariance
+    under the ray-queue chunk size, and the ray-count identities."""
+    cfg, flat, _ = bench.build_workload(key)
+    npix = cfg.width * cfg.height
+    n_lights = int(flat.lights.shape[0])
+    counts = ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written")
+    a0, p0, s0 = gpu_render(cfg, flat)
+    assert s0["rays_primary"] == npix * cfg.aa_total_rays
+    per_hit = n_lights * cfg.point_light_multiplicator
+    assert s0["rays_shadow"] % per_hit == 0
+    n_hits = s0["rays_shadow"] // per_hit
+    n_rays = s0["rays_primary"] + s0["rays_reflection"] + s0["rays_refraction"]
+    assert s0["pixels_written"] <= n_hits <= n_rays
+    assert s0["pixels_written"] == int((a0 != 0).sum())
+    a1, _, s1 = gpu_render(cfg, flat, aux=False)
+    assert np.array_equal(a0, a1), "render is not deterministic"
+    assert all(s1[k] == s0[k] for k in counts)
+    acc = np.zeros_like(a0)
+    tot = {k: 0 for k in counts}
+    for rank in range(3):
+        ar, _, sr = gpu_render(cfg, flat, n_ranks=3, rank=rank, aux=False)
+        assert not (acc[ar != 0] != 0).any(), "tiles of two ranks overlap"
+        acc |= ar
+        for k in tot:
+            tot[k] += sr[k]
+    assert np.array_equal(acc, a0), "union of the ranks' tiles differs from the single-GPU frame"
+    assert all(tot[k] == s0[k] for k in tot), (tot, s0)
+    # rays per launch 2^20 instead of the whole frame: many primary batches, multi-chunk levels
+    a3, _, s3 = gpu_render(cfg, flat, aux=False, chunk_log2=20)
+    assert np.array_equal(a3, a0) and all(s3[k] == s0[k] for k in counts)
+    # 9 distinct sample origins among 24: tracing every repeat (and all their children) takes the same decisions
+    # (colour: up to the rounding of the wavefront-level arrival fast path)
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    a4, _, s4 = gpu_render(cfg, flat, aux=False, no_aa_dedup=1)
+    assert np.abs(ch(a4) - ch(a0)).max() <= 1 and np.array_equal(a4 != 0, a0 != 0) and all(s4[k] == s0[k] for k in counts)
+    assert s4["rays_traced"] == n_rays and s0["rays_traced"] * 24 == n_rays * 9
+    # every (wavefront, light) set "overflows": one BVH walk per sample, none of the beam-level shortcuts
+    a2, p2, s2 = gpu_render(cfg, flat, shadow_candidate_cap=_abi.RT_CAND_CAP_NONE)
+    assert np.array_equal(p2["hit_id"], p0["hit_id"]) and np.array_equal(p2["hit_t"], p0["hit_t"])
+    assert all(s2[k] == s0[k] for k in counts)
+    d = np.abs(p2["rgb"] - p0["rgb"]).max()
+    assert d <= 4e-6, d
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    assert np.abs(ch(a2) - ch(a0)).max() <= 1
+    print(f"{key}: {n_rays} rays, {s0['rays_shadow']} shadow rays, kernel {s0['kernel_ms']:.1f} ms; "
+          f"per-sample walks {s2['kernel_ms']:.1f} ms; 2^20-ray chunks {s3['kernel_ms']:.1f} ms")
+
+
+def test_config4_full_size_properties():
+    _full_size_properties("c4")
+
+
+def test_config5_full_size_properties():
+    _full_size_properties("c5")
+
+
+def test_renderer_never_reuses_a_stale_device_scene():
+    """One renderer, a scene that is mutated between renders, and two different temporaries: every render must see
+    the scene it was given (the reference's render(&buffer, &scene) reads the scene on every call)."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.f32math import Vec3
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import ColorType, SphereData
+    cfg = RenderConfig.from_features([], width_override=160, height_override=128)
+    r = RaytracerRenderer(cfg, device=0)
+
+    def render(scene):
+        buf = ImageBuffer.new(cfg.width, cfg.height)
+        r.render(buf, scene)
+        return buf.buffer.copy()
+
+    scene = scenes.test_scene(cfg)
+    a = render(scene)
+    assert np.array_equal(a, render(scene))
+    flat0 = scene.flatten()
+    scene.add_sphere(SphereData.new(Vec3(0.5, float(cfg.scene_height) * 0.5, 0.2), 0.2, ColorType(1.0, 0.1, 0.1)))
+    b = render(scene)
+    assert not np.array_equal(a, b), "the added sphere did not show up: stale device scene"
+    fresh = RaytracerRenderer(cfg, device=0)
+    buf = ImageBuffer.new(cfg.width, cfg.height)
+    fresh.render(buf, scene)
+    assert np.array_equal(b, buf.buffer)
+    # temporaries (their id() may be recycled)
+    assert np.array_equal(render(flat0), a)
+    assert np.array_equal(render(scene.flatten()), b)
+    assert np.array_equal(render(scenes.test_scene(cfg).flatten().without_triangles()), render(scenes.test_scene(cfg).flatten().without_triangles()))
+
+
+def test_repeated_aa_samples_are_traced_once_with_identical_results():
+    """Ragged cases of the sample de-duplication: a window that is not aligned to anything, secondary rays (children
+    carry the multiplicity into the fixed-point pixel sums), a random table without repeats, and a hand-made table
+    whose repeats are interleaved."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], n_cloud_sets=16, depth_override=4)
+    flat = scenes.test_scene(cfg).flatten()
+    win = (297, 203, 53, 37)
+    a0, p0, s0 = gpu_render(cfg, flat, win)
+    a1, p1, s1 = gpu_render(cfg, flat, win, no_aa_dedup=1)
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    # (same decisions; the colour may move by the rounding of the wavefront-level arrival fast path)
+    assert np.abs(ch(a0) - ch(a1)).max() <= 1 and np.abs(p0["rgb"] - p1["rgb"]).max() <= 2e-6 and np.array_equal(p0["hit_t"], p1["hit_t"])
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
+        assert s0[k] == s1[k], k
+    assert s1["rays_traced"] == s1["rays_primary"] + s1["rays_reflection"] + s1["rays_refraction"]
+    assert s0["rays_traced"] * 16 == s1["rays_traced"] * 9
+    compare(cfg, flat, win)
+    # no repeats: nothing to merge
+    cfg_r = RenderConfig.from_features(["anti_aliasing_randomness", "anti_aliasing_rotation_scale", "reflections"])
+    _, _, sr = gpu_render(cfg_r, scenes.test_scene(cfg_r).flatten(), (300, 200, 40, 30))
+    assert sr["rays_traced"] == sr["rays_primary"] + sr["rays_reflection"]
+    # interleaved repeats, 11 samples (ragged 8-lane chunks), -0 == +0
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import sampling
+    base = sampling.aa_offsets(cfg)
+    tab = np.stack([base[3], base[0], base[3], base[5], -base[0], base[5], base[3], base[1], base[8], base[1], base[3]])
+    buf = ImageBuffer.new(cfg.width, cfg.height)
+    r = RaytracerRenderer(cfg, device=0)
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    outs = []
+    for nd in (0, 1):
+        p, keep = _abi.make_params(cfg, aa_offsets=tab, window=win, tuning=dict(no_aa_dedup=nd))
+        b = ImageBuffer.new(cfg.width, cfg.height)
+        st = _abi.rt_stats()
+        _lib.check(_lib.load().rt_render(r.device_scene(flat).handle, C.byref(p), b.buffer.ctypes.data, None, C.byref(st)))
+        outs.append((b.buffer.copy(), st.as_dict()))
+    assert np.abs(ch(outs[0][0]) - ch(outs[1][0])).max() <= 1
+    assert outs[0][1]["rays_primary"] == outs[1][1]["rays_primary"] == 11 * win[2] * win[3]
+    assert outs[0][1]["rays_shadow"] == outs[1][1]["rays_shadow"]
+    argb_o, _, so = oracle_lib.render(flat, cfg, window=win, aa_offsets=tab, aux=False)
+    assert so["rays_primary"] == outs[0][1]["rays_primary"] and so["rays_shadow"] == outs[0][1]["rays_shadow"]
+    assert np.abs(ch(outs[0][0]) - ch(argb_o)).max() <= 1

@@ -46,7 +46,9 @@ for spec in args or ["c3"]:
         import dataclasses
         flat = dataclasses.replace(flat, lights=flat.lights[: int(os.environ["RT_AB_LIGHTS"])])
     ds = DeviceScene(flat, 0)
-    p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank)
+    # RT_AB_TUNING="no_aa_dedup=1,chunk_log2=20": rt_tuning fields
+    tuning = {k: int(v, 0) for k, v in (kv.split("=") for kv in os.environ.get("RT_AB_TUNING", "").split(",") if kv)}
+    p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank, tuning=tuning)
     if os.environ.get("RT_AB_TILE"):  # experiments: ownership tile size of the multi-GPU partition
         p.tile_size = int(os.environ["RT_AB_TILE"])
     fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
@@ -63,7 +65,7 @@ for spec in args or ["c3"]:
     _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
     rays = st.rays_primary + st.rays_reflection + st.rays_refraction
     ms = float(np.median(times))
-    print(f"{spec:28s} kernel {ms:10.3f} ms  (min {min(times):.3f})  rays {rays:>11d}  shadow {st.rays_shadow:>13d}  "
+    print(f"{spec:28s} kernel {ms:10.3f} ms  (min {min(times):.3f})  rays {rays:>11d} (traced {st.rays_traced})  shadow {st.rays_shadow:>13d}  "
           f"simd_eff {st.wave_ray_lanes/max(1, 64*st.wave_ray_passes):.3f}  {rays/ms/1e3:8.1f} Mray/s  {st.rays_shadow/ms/1e6:7.2f} Gshadow/s  checksum {int(fb.to(torch.int64).sum()) & 0xFFFFFFFF:08x}")
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
