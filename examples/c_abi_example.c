@@ -1,6 +1,8 @@
 /*
  * c_abi_example.c -- the drop-in boundary used from plain C (what a Rust/cgo/JNI binding does):
- * builds a two-object scene, renders 96x80 through rt_scene_create / rt_render and prints a checksum.
+ * builds a two-object scene, renders 96x80 through rt_scene_create / rt_render and prints a checksum; then renders
+ * the same frame through the multi-GPU entry point rt_render_multi (n_gpu = 1, and 3 tile-partitioned "ranks" on the one
+ * GPU as a rehearsal of the gather) and checks that the images are identical.
  *
  *   gcc -I include examples/c_abi_example.c -L hslu_i/ba_raytracing/f2501_raytracer_amd -lrt_hip \
  *       -Wl,-rpath,$PWD/hslu_i/ba_raytracing/f2501_raytracer_amd -o /tmp/c_abi_example
@@ -85,8 +87,41 @@ int main(void) {
   printf("pixels written %llu of %u, rays %llu, shadow rays %llu, checksum %llx, kernel %.3f ms\n",
          (unsigned long long)st.pixels_written, p.width * p.height, (unsigned long long)st.rays_primary,
          (unsigned long long)st.rays_shadow, sum, st.kernel_ms);
+  /* the multi-GPU side of Renderer::render: one process, n scenes (one per GPU), one gather to the root */
+  int bad = 0;
+  {
+    uint32_t* multi = (uint32_t*)calloc((size_t)p.width * p.height, 4);
+    rt_scene* one[1] = {scene};
+    rt_stats sm;
+    if (rt_render_multi(one, 1, &p, multi, &sm) != RT_OK) {
+      fprintf(stderr, "rt_render_multi(1): %s\n", rt_last_error());
+      return 1;
+    }
+    bad |= memcmp(multi, argb, (size_t)p.width * p.height * 4) != 0 || sm.pixels_written != st.pixels_written;
+    /* three tile-partitioned ranks rehearsed on the one GPU (16x16 tiles so that every rank owns some) */
+    rt_scene* three[3] = {scene, NULL, NULL};
+    if (rt_scene_create(&d, 0, &three[1]) != RT_OK || rt_scene_create(&d, 0, &three[2]) != RT_OK) {
+      fprintf(stderr, "rt_scene_create: %s\n", rt_last_error());
+      return 1;
+    }
+    rt_params p3 = p;
+    p3.tile_size = 16;
+    memset(multi, 0, (size_t)p.width * p.height * 4);
+    if (rt_render_multi(three, 3, &p3, multi, &sm) != RT_OK) {
+      fprintf(stderr, "rt_render_multi(3): %s\n", rt_last_error());
+      return 1;
+    }
+    bad |= memcmp(multi, argb, (size_t)p.width * p.height * 4) != 0 || sm.pixels_written != st.pixels_written ||
+           sm.rays_primary != st.rays_primary;
+    printf("rt_render_multi: 1 GPU and 3 ranks on one GPU %s rt_render (gather %.3f ms, d2h %.3f ms)\n",
+           bad ? "DIFFER from" : "match", sm.gather_ms, sm.d2h_ms);
+    rt_multi_release();
+    rt_scene_destroy(three[1]);
+    rt_scene_destroy(three[2]);
+    free(multi);
+  }
   rt_scene_destroy(scene);
   free(argb);
   /* pixels whose ray misses everything keep the caller's background, as in the reference */
-  return (st.pixels_written > 0 && st.rays_primary == (uint64_t)p.width * p.height) ? 0 : 2;
+  return (!bad && st.pixels_written > 0 && st.rays_primary == (uint64_t)p.width * p.height) ? 0 : 2;
 }

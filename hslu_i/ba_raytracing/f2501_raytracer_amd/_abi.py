@@ -63,7 +63,7 @@ class rt_stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_reflection", C.c_uint64), ("rays_refraction", C.c_uint64),
         ("rays_shadow", C.c_uint64), ("pixels_written", C.c_uint64), ("rays_traced", C.c_uint64),
-        ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("d2h_ms", C.c_double),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("d2h_ms", C.c_double), ("gather_ms", C.c_double),
         ("wave_ray_passes", C.c_uint64), ("wave_ray_lanes", C.c_uint64),
         ("wave_nearest_nodes", C.c_uint64), ("wave_nearest_tris", C.c_uint64),
         ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
@@ -72,6 +72,20 @@ class rt_stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rt_gather_info(C.Structure):
+    _fields_ = [
+        ("render_ms", C.c_double), ("gather_ms", C.c_double), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
+        ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("tiles_owned", C.c_uint32), ("transport", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+RT_COMM_ID_BYTES = 128
+RT_TRANSPORT_NONE, RT_TRANSPORT_RCCL, RT_TRANSPORT_LOCAL = 0, 1, 2
 
 
 class rt_bvh_info(C.Structure):

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._abi import rt_aux, rt_bvh_info, rt_params, rt_scene_desc, rt_stats
+from ._abi import rt_aux, rt_bvh_info, rt_gather_info, rt_params, rt_scene_desc, rt_stats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_HIP_LIB selects a diagnostic build of the same library (tools/, A/B timing); default: in-tree
@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 EXPORTS = (
     "rt_device_count", "rt_scene_create", "rt_render", "rt_render_device", "rt_render_collect_stats",
     "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info",
+    "rt_gather_layout", "rt_render_multi", "rt_multi_release", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy",
+    "rt_render_gather_device", "rt_comm_last_gather",
 )
 
 _lib = None
@@ -48,6 +50,22 @@ def load():
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_scene_bvh_info.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(rt_bvh_info)]
+    u32p = C.POINTER(C.c_uint32)
+    lib.rt_gather_layout.restype = C.c_int
+    lib.rt_gather_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.rt_render_multi.restype = C.c_int
+    lib.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(rt_params), C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_multi_release.restype = None
+    lib.rt_comm_unique_id.restype = C.c_int
+    lib.rt_comm_unique_id.argtypes = [C.c_void_p]
+    lib.rt_comm_create.restype = C.c_int
+    lib.rt_comm_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    lib.rt_comm_destroy.restype = None
+    lib.rt_comm_destroy.argtypes = [C.c_void_p]
+    lib.rt_render_gather_device.restype = C.c_int
+    lib.rt_render_gather_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(rt_params), C.c_void_p, C.c_void_p]
+    lib.rt_comm_last_gather.restype = C.c_int
+    lib.rt_comm_last_gather.argtypes = [C.c_void_p, C.POINTER(rt_gather_info)]
     _lib = lib
     return lib
 

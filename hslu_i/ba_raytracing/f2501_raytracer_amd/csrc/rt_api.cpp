@@ -15,13 +15,11 @@
 #include <string>
 #include <vector>
 
-#include "rt_internal.h"
-
-namespace {
+#include "rt_host.h"
 
 thread_local std::string g_err;
 
-int fail(int code, const char* fmt, ...) {
+int rt_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -30,66 +28,6 @@ int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                          \
-  do {                                                                                         \
-    hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess)                                                                      \
-      return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s", #expr, \
-                  hipGetErrorString(e_));                                                      \
-  } while (0)
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return RT_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes < 256 ? 256 : bytes;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return fail(RT_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    }
-    cap = want;
-    return RT_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-}  // namespace
-
-struct rt_scene {
-  int device = 0;
-  RtDevScene dev{};
-  rt_bvh_info info{};
-  DevBuf blob;  // spheres, triangles, materials, lights, BVH (RtDevScene offsets)
-  // per-render workspaces
-  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
-  std::vector<uint32_t> sup_host;
-  uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
-  size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
-  uint32_t chunk = 1u << 16;  // rays per secondary launch / primary batch of the current frame
-  float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)
-  // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
-  std::vector<float> aa_host, cloud_host, cloud_scaled;
-  std::vector<uint32_t> aa_table;  // device image: [2U] offsets (float bits), [U] multiplicities, [n] sample -> thread
-  uint32_t aa_unique = 0;
-  bool aa_dedup = true;
-  // The tables are uploaded on the stream of the call that changed them; a later call on another stream waits for
-  // that upload (tables_ev) before its kernels read them.
-  hipEvent_t tables_ev = nullptr;
-  hipStream_t tables_stream = nullptr, last_stream = nullptr;
-  bool tables_pending = false, rendered = false;
-  float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
-  float cloud_ball_f[3] = {0.f, 0.f, 0.f};
-};
 
 extern "C" {
 
@@ -325,7 +263,9 @@ int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
   return RT_OK;
 }
 
-static int validate_params(const rt_params* p) {
+}  // extern "C"
+
+int rt_validate_params(const rt_params* p) {
   if (!p) return fail(RT_ERR_INVALID_ARG, "null params");
   if (p->abi_version != RT_ABI_VERSION)
     return fail(RT_ERR_INVALID_ARG, "rt_params.abi_version %u != %u", p->abi_version, RT_ABI_VERSION);
@@ -348,6 +288,8 @@ static int validate_params(const rt_params* p) {
     return fail(RT_ERR_INVALID_ARG, "tuning.chunk_log2 outside 10..26");
   return RT_OK;
 }
+
+extern "C" {
 
 // fills the device parameter block, uploading tables / sizing workspaces as needed
 static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, hipStream_t stream,
@@ -686,7 +628,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
 
 int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, void* hip_stream) {
   if (!s || !argb_dev) return fail(RT_ERR_INVALID_ARG, "null argument");
-  int rc = validate_params(p);
+  int rc = rt_validate_params(p);
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(s->device));
   RtDevParams P;
@@ -720,19 +662,10 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   return RT_OK;
 }
 
-namespace {
-struct EventPair {  // destroyed on every return path
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  ~EventPair() {
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-  }
-};
-}  // namespace
 
 int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux, rt_stats* stats) {
   if (!s || !argb) return fail(RT_ERR_INVALID_ARG, "null argument");
-  int rc = validate_params(p);
+  int rc = rt_validate_params(p);
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(s->device));
   auto t_begin = std::chrono::steady_clock::now();
@@ -801,3 +734,17 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
 }
 
 }  // extern "C"
+
+int rt_render_device_staged(rt_scene* s, const rt_params* p, uint32_t* out_dev, const uint32_t* stage_slot,
+                            uint32_t tiles_x, hipStream_t stream) {
+  if (!s || !out_dev) return fail(RT_ERR_INVALID_ARG, "null argument");
+  int rc = rt_validate_params(p);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  RtDevParams P;
+  if ((rc = prepare(s, p, out_dev, nullptr, stream, &P)) != RT_OK) return rc;
+  P.stage_slot = stage_slot;
+  P.stage_tiles_x = tiles_x;
+  return render_frame(s, P, stream, p->tuning.chunk_log2);
+}
+

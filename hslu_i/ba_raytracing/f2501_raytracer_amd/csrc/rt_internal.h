@@ -100,6 +100,10 @@ struct RtDevParams {
   uint32_t tile_size, n_ranks, rank;
   uint32_t traversal;
   // outputs
+  // multi-GPU: with stage_slot != nullptr `argb` is this rank's compact staging buffer and pixel (gx, gy) of tile
+  // (tx, ty) goes to stage_slot[ty * stage_tiles_x + tx] * tile_size^2 + (gy % tile_size) * tile_size + gx % tile_size
+  const uint32_t* stage_slot;
+  uint32_t stage_tiles_x;
   uint32_t* argb;
   float* aux_rgb;
   int32_t* aux_hit_id;
@@ -143,3 +147,6 @@ int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n,
                   void* tmp, size_t* tmp_bytes, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
+// multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame
+int rt_launch_scatter(uint32_t* argb, const uint32_t* recv, const uint32_t* rank_off, const uint32_t* tile_slot, uint32_t width,
+                      uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t n_ranks, void* stream);

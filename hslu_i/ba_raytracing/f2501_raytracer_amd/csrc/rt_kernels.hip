@@ -1527,6 +1527,13 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   return out;
 }
 
+// where the packed pixel (gx, gy) is stored: the W x H frame, or this rank's compact tile staging (multi-GPU gather)
+__device__ __forceinline__ uint32_t out_index(const RtDevParams& P, uint32_t gx, uint32_t gy, uint32_t pix) {
+  if (!P.stage_slot) return pix;  // wave-uniform (kernel argument)
+  const uint32_t ts = P.tile_size, tx = gx / ts, ty = gy / ts;
+  return P.stage_slot[ty * P.stage_tiles_x + tx] * ts * ts + (gy - ty * ts) * ts + (gx - tx * ts);
+}
+
 __device__ __forceinline__ uint32_t pack_argb(V3 c) {
   return 0xFF000000u | (to_u8(c.x) << 16) | (to_u8(c.y) << 8) | to_u8(c.z);
 }
@@ -1673,7 +1680,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
         acc_add(P, pix, color, 1u);
         P.acc[4 * (size_t)pix + 3] = 1;
       } else {
-        P.argb[pix] = pack_argb(color);
+        P.argb[out_index(P, pm2.gx, pm2.gy, pix)] = pack_argb(color);
         if (P.aux_rgb) {
           P.aux_rgb[3 * (size_t)pix + 0] = color.x;
           P.aux_rgb[3 * (size_t)pix + 1] = color.y;
@@ -1844,7 +1851,7 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
   unsigned long long wrote = 0;
   if (f) {
     V3 c = mk((float)r * RT_ACC_INV_SCALE, (float)g * RT_ACC_INV_SCALE, (float)b * RT_ACC_INV_SCALE);
-    P.argb[pix] = pack_argb(c);
+    P.argb[out_index(P, gx, gy, pix)] = pack_argb(c);
     if (P.aux_rgb) {
       P.aux_rgb[3 * (size_t)pix + 0] = c.x;
       P.aux_rgb[3 * (size_t)pix + 1] = c.y;

@@ -188,6 +188,7 @@ typedef struct rt_stats {
   double kernel_ms; /* device time of the render kernel(s) (CPU oracle: wall time) */
   double total_ms;  /* wall time of the call incl. copies */
   double d2h_ms;    /* rt_render / rt_render_multi: wall time of the device -> host copy of the packed pixels */
+  double gather_ms; /* rt_render_multi: device time of the tile gather on the root (RCCL recv + scatter kernel) */
   /* The wave_* work statistics below are filled only by the statistics build of the library
    * (`make STATS=1` -> librt_hip_stats.so, used by tools/perf_ab.py); the shipped kernels leave them 0.
    * GPU only (0 from the CPU oracle): SIMD efficiency of the ray loop.  wave_ray_passes = number of
@@ -289,6 +290,62 @@ typedef struct rt_bvh_info {
   uint32_t n_references; /* triangle references in the leaves (>= n_triangles: split clipping) */
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
+
+/* ---- multi-GPU: tile-partitioned frame + ONE gather of the packed pixels to rank 0 (RCCL over xGMI) ---------
+ *
+ * Reference: Renderer::render hands RENDER_STRIDE tiles to rayon workers that all write one ImageBuffer
+ * (src/renderer/mod.rs:80-94,146-209, src/image_buffer.rs:48-97).  Here rank r renders the tiles with
+ * rt_tile_owner(tx, ty, n_ranks) == r on its own GPU (scene replicated), straight into a rank-compact staging
+ * buffer; the gather is one ncclGroupStart / ncclRecv x (n-1) on the root, ncclSend on the others / ncclGroupEnd --
+ * every peer sends over its own xGMI link, no ring -- followed by a scatter kernel on the root.  No other
+ * communication exists on the path.
+ *
+ * Staging layout (ABI spec): a rank's staging buffer holds its tiles in row-major tile order, each as
+ * tile_size x tile_size pixels, row-major inside the tile (edge tiles padded); a staged 0 = "no hit" (the pixel
+ * keeps the caller's fill).  rt_gather_layout computes it on the host (no GPU needed). */
+
+/* tile_slot[ty * tiles_x + tx] = index of tile (tx, ty) inside its owner's staging buffer; tiles_per_rank[r] =
+ * number of tiles rank r owns.  tiles_x = ceil(width / tile_size).  Either output may be NULL.  tile_size 0 -> 48. */
+int rt_gather_layout(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t n_ranks, uint32_t* tile_slot,
+                     uint32_t* tiles_per_rank);
+
+/* (a) ONE process drives all GPUs -- the shape of the reference's single-process Renderer::render.  per_gpu[i] is
+ * the same scene created on GPU i (rt_scene_create(desc, device_i, ...)); per_gpu[0]'s GPU is the root.  argb is a
+ * HOST buffer, W*H, as in rt_render; params->n_ranks / rank are ignored (n_gpu and i are used).  Blocks until argb is
+ * complete.  stats (nullable): ray counters summed over the GPUs, kernel_ms = slowest GPU's render, gather_ms, d2h_ms.
+ * n_gpu == 1 is rt_render without aux planes.  Scenes on distinct GPUs use RCCL; several scenes on ONE GPU (only
+ * useful to rehearse the tile logic on a single-GPU machine) are gathered with device-to-device copies. */
+int rt_render_multi(rt_scene* const* per_gpu, int n_gpu, const rt_params* params, uint32_t* argb, rt_stats* stats);
+/* frees the communicators / staging buffers rt_render_multi caches between calls (optional) */
+void rt_multi_release(void);
+
+/* (b) one process per GPU (torch.distributed / MPI style launchers): rank 0 makes an id, the host ships its 128 bytes
+ * to the other ranks by any out-of-band means, every rank creates its communicator (collective call). */
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm rt_comm;
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+int rt_comm_create(const uint8_t* id, uint32_t n_ranks, uint32_t rank, int device, rt_comm** out); /* n_ranks 1: id may be NULL */
+void rt_comm_destroy(rt_comm* comm);
+/* Renders this rank's tiles and takes part in the gather; everything is enqueued on hip_stream (with reflections /
+ * refractions the render part synchronises the stream between ray-queue levels, as rt_render_device does).  On rank 0
+ * argb_dev (DEVICE, W*H, pre-filled by the caller) holds the complete frame once the stream has drained; on the
+ * other ranks it is not touched and may be NULL.  params->n_ranks / rank are ignored (the communicator's are used). */
+int rt_render_gather_device(rt_scene* scene, rt_comm* comm, const rt_params* params, uint32_t* argb_dev, void* hip_stream);
+
+#define RT_TRANSPORT_NONE 0u  /* one rank: nothing to gather */
+#define RT_TRANSPORT_RCCL 1u  /* ncclSend / ncclRecv */
+#define RT_TRANSPORT_LOCAL 2u /* rt_render_multi with several scenes on one GPU: device-to-device copies */
+typedef struct rt_gather_info {
+  double render_ms;        /* device time of this rank's render kernels in the last call */
+  double gather_ms;        /* device time from the end of the render to the end of send / recv (+ scatter on the root) */
+  uint64_t bytes_sent;     /* by this rank in the last call */
+  uint64_t bytes_received; /* root only */
+  uint32_t n_ranks, rank;  /* as RCCL reports them (ncclCommCount / ncclCommUserRank) when transport is RCCL */
+  uint32_t tiles_owned;
+  uint32_t transport; /* RT_TRANSPORT_* */
+} rt_gather_info;
+/* timings / sizes of the last rt_render_gather_device on this communicator; call after the stream has drained */
+int rt_comm_last_gather(rt_comm* comm, rt_gather_info* out);
 
 #ifdef __cplusplus
 }

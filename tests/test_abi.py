@@ -40,15 +40,17 @@ def test_ctypes_layout_matches_header(tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "rt_hip.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(rt_scene_desc), sizeof(rt_params), sizeof(rt_aux),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(rt_scene_desc), sizeof(rt_params), sizeof(rt_aux),"
         " sizeof(rt_stats), sizeof(rt_bvh_info), offsetof(rt_params, aa_offsets), offsetof(rt_params, cloud_sets),"
-        " offsetof(rt_params, traversal)); return 0;}\n")
+        " offsetof(rt_params, traversal), offsetof(rt_params, tuning), offsetof(rt_scene_desc, bvh), sizeof(rt_gather_info),"
+        " offsetof(rt_stats, rays_traced), offsetof(rt_stats, gather_ms)); return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_abi.rt_scene_desc), C.sizeof(_abi.rt_params), C.sizeof(_abi.rt_aux), C.sizeof(_abi.rt_stats),
             C.sizeof(_abi.rt_bvh_info), _abi.rt_params.aa_offsets.offset, _abi.rt_params.cloud_sets.offset,
-            _abi.rt_params.traversal.offset]
+            _abi.rt_params.traversal.offset, _abi.rt_params.tuning.offset, _abi.rt_scene_desc.bvh.offset,
+            C.sizeof(_abi.rt_gather_info), _abi.rt_stats.rays_traced.offset, _abi.rt_stats.gather_ms.offset]
     assert got == want
 
 
@@ -102,3 +104,5 @@ def test_c_example_renders_on_the_gpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rays 7680," in out.stdout and "pixels written 0 " not in out.stdout
+    # the multi-GPU entry point with n_gpu = 1 and with 3 tile-partitioned ranks rehearsed on the one GPU
+    assert "rt_render_multi: 1 GPU and 3 ranks on one GPU match rt_render" in out.stdout

@@ -621,3 +621,82 @@ def test_repeated_aa_samples_are_traced_once_with_identical_results():
     argb_o, _, so = oracle_lib.render(flat, cfg, window=win, aa_offsets=tab, aux=False)
     assert so["rays_primary"] == outs[0][1]["rays_primary"] and so["rays_shadow"] == outs[0][1]["rays_shadow"]
     assert np.abs(ch(outs[0][0]) - ch(argb_o)).max() <= 1
+
+
+# ---- the multi-GPU side of the boundary (rt_render_multi / rt_comm_*), rehearsed on the one GPU --------------------
+def render_multi(cfg, flat, n_ranks, window=None, fill=0, tile_size=None):
+    """rt_render_multi with `n_ranks` scenes on device 0 (several ranks on one GPU: the tile partition, the compact
+    staging written by the kernels and the scatter are exercised; the transport is device-to-device copies)."""
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    lib = _lib.load()
+    scenes_ = [DeviceScene(flat, 0) for _ in range(n_ranks)]
+    p, keep = _abi.make_params(cfg, window=window)
+    if tile_size:
+        p.tile_size = tile_size
+    buf = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+    st = _abi.rt_stats()
+    arr = (C.c_void_p * n_ranks)(*[s.handle for s in scenes_])
+    _lib.check(lib.rt_render_multi(arr, n_ranks, C.byref(p), buf.buffer.ctypes.data, C.byref(st)))
+    for s in scenes_:
+        s.close()
+    return buf.buffer.copy(), st.as_dict()
+
+
+@pytest.mark.parametrize("features,kw", [
+    ([], {}),                                                          # direct store, no AA
+    (["anti_aliasing", "soft_shadows"], dict(n_cloud_sets=16)),         # direct store from the per-pixel LDS sum
+    (["realistic", "anti_aliasing"], dict(depth_override=4)),           # ray streaming: stores by rt_resolve_kernel
+])
+def test_render_multi_equals_render(features, kw):
+    cfg = RenderConfig.from_features(features, **kw)
+    flat = scenes.test_scene(cfg).flatten()
+    fill = 0x00ABCDEF
+    ref = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+    r = RaytracerRenderer(cfg, device=0)
+    r.render(ref, flat)
+    counts = ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written", "rays_traced")
+    for n in (1, 2, 3, 5):
+        got, st = render_multi(cfg, flat, n, fill=fill)
+        assert np.array_equal(got, ref.buffer), f"{n} ranks: {(got != ref.buffer).sum()} pixels differ"
+        assert all(st[k] == r.last_stats[k] for k in counts), (n, st, r.last_stats)
+        assert st["kernel_ms"] > 0 and st["d2h_ms"] > 0
+    # a window that cuts tiles, small tiles, ragged frame edge
+    win = (cfg.width - 101, cfg.height - 77, 101, 77)
+    ref2 = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+    r.render(ref2, flat, window=win)
+    got, _ = render_multi(cfg, flat, 3, window=win, fill=fill, tile_size=16)
+    assert np.array_equal(got, ref2.buffer)
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    _lib.load().rt_multi_release()
+
+
+def test_render_gather_device_single_rank_and_errors():
+    """The process-per-GPU entry points with one rank (no RCCL traffic): rt_comm_create / rt_render_gather_device /
+    rt_comm_last_gather, HBM-resident frame."""
+    import ctypes as C
+    import torch
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.distributed import RcclGather
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    cfg = RenderConfig.from_features(["anti_aliasing"])
+    flat = scenes.test_scene(cfg).flatten()
+    ref, _, st = gpu_render(cfg, flat, aux=False)
+    ds = DeviceScene(flat, 0)
+    g = RcclGather(1, 0, 0)
+    p, keep = _abi.make_params(cfg, n_ranks=7, rank=3)  # ignored: the communicator's are used
+    fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device="cuda:0")
+    g.render_gather(ds, p, fb.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(fb.cpu().numpy().view(np.uint32), ref)
+    info = g.last()
+    assert info["n_ranks"] == 1 and info["rank"] == 0 and info["transport"] == _abi.RT_TRANSPORT_NONE
+    assert info["render_ms"] > 0 and info["bytes_sent"] == 0 and info["tiles_owned"] == -(-cfg.width // 48) * -(-cfg.height // 48)
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_comm_create(None, 2, 0, 0, C.byref(h)) == _abi.RT_ERR_INVALID_ARG  # id missing
+    assert lib.rt_comm_create(None, 1, 1, 0, C.byref(h)) == _abi.RT_ERR_INVALID_ARG  # rank out of range
+    assert lib.rt_render_multi(None, 1, C.byref(p), fb.data_ptr(), None) == _abi.RT_ERR_INVALID_ARG
+    g.close()
+    ds.close()
