@@ -33,6 +33,11 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
 
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_build_id(void) { return RT_BUILD_ID; }
+
 int rt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -279,6 +279,10 @@ void rt_scene_destroy(rt_scene* scene);
 /* thread-local message for the last non-RT_OK return on this thread */
 const char* rt_last_error(void);
 
+/* hash of the sources and flags this library was built from (profiles/ summaries record it: a rocprof summary is
+ * only quoted for the build it was taken on) */
+const char* rt_build_id(void);
+
 /* introspection for DESIGN.md / tests: BVH size of a created scene */
 typedef struct rt_bvh_info {
   uint32_t n_nodes;

@@ -18,8 +18,9 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(ORACLE_DIR, "rt_oracle.c")
-    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("rt_oracle.c", "rt_simd_baseline.c", "Makefile")] + \
+        [os.path.join(ROOT, "include", "rt_hip.h")]
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return SO
 
@@ -33,6 +34,8 @@ def load():
     lib.rt_cpu_render.restype = C.c_int
     lib.rt_cpu_render.argtypes = [C.POINTER(_abi.rt_scene_desc), C.POINTER(_abi.rt_params), C.c_void_p,
                                   C.POINTER(_abi.rt_aux), C.POINTER(_abi.rt_stats), C.c_int]
+    lib.rt_simd_render.restype = C.c_int
+    lib.rt_simd_render.argtypes = lib.rt_cpu_render.argtypes
     fp = C.POINTER(C.c_float)
     lib.rt_oracle_sphere.restype = C.c_int
     lib.rt_oracle_sphere.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_uint32, fp, fp, C.c_int, fp]
@@ -50,8 +53,23 @@ def load():
     return lib
 
 
-def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, aa_offsets=None, cloud=None):
-    """Brute-force CPU render of `window` (x0,y0,w,h) of the frame.  Returns (argb, planes, stats)."""
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup quota (a GPU box shows 256 CPUs in
+    /proc and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, aa_offsets=None, cloud=None, impl="scalar"):
+    """Brute-force CPU render of `window` (x0,y0,w,h) of the frame.  impl: "scalar" = the parity oracle
+    (rt_oracle.c), "simd" = the 8-lane AVX2 packet baseline over 48x48 tiles (rt_simd_baseline.c).
+    Returns (argb, planes, stats)."""
     lib = load()
     desc, keep = _abi.make_scene_desc(flat)
     p, keep2 = _abi.make_params(cfg, aa_offsets=aa_offsets, cloud=cloud, window=window, n_ranks=n_ranks, rank=rank)
@@ -62,8 +80,9 @@ def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, 
     a.rgb, a.hit_id, a.hit_t = planes["rgb"].ctypes.data, planes["hit_id"].ctypes.data, planes["hit_t"].ctypes.data
     st = _abi.rt_stats()
     if n_threads is None:
-        n_threads = min(os.cpu_count() or 1, 16)
-    rc = lib.rt_cpu_render(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st), int(n_threads))
+        n_threads = min(host_cores(), 16)
+    fn = lib.rt_simd_render if impl == "simd" else lib.rt_cpu_render
+    rc = fn(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st), int(n_threads))
     if rc != 0:
         raise RuntimeError(f"rt_cpu_render failed: {rc}")
     return argb, planes, st.as_dict()

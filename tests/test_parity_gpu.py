@@ -676,7 +676,6 @@ def test_render_gather_device_single_rank_and_errors():
     """The process-per-GPU entry points with one rank (no RCCL traffic): rt_comm_create / rt_render_gather_device /
     rt_comm_last_gather, HBM-resident frame."""
     import ctypes as C
-    import torch
     from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
     from hslu_i.ba_raytracing.f2501_raytracer_amd.distributed import RcclGather
     from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
@@ -686,10 +685,18 @@ def test_render_gather_device_single_rank_and_errors():
     ds = DeviceScene(flat, 0)
     g = RcclGather(1, 0, 0)
     p, keep = _abi.make_params(cfg, n_ranks=7, rank=3)  # ignored: the communicator's are used
-    fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device="cuda:0")
-    g.render_gather(ds, p, fb.data_ptr(), None)
-    torch.cuda.synchronize()
-    assert np.array_equal(fb.cpu().numpy().view(np.uint32), ref)
+    # a device frame buffer straight from the HIP runtime the library itself is linked against (importing torch after
+    # librt_hip.so would pull in a second, mismatching runtime)
+    hip = C.CDLL("libamdhip64.so.7")
+    nbytes = cfg.width * cfg.height * 4
+    fb = C.c_void_p()
+    assert hip.hipMalloc(C.byref(fb), C.c_size_t(nbytes)) == 0
+    assert hip.hipMemset(fb, 0, C.c_size_t(nbytes)) == 0
+    g.render_gather(ds, p, fb.value, None)
+    assert hip.hipDeviceSynchronize() == 0
+    got = np.zeros(cfg.width * cfg.height, np.uint32)
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fb, C.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
+    assert np.array_equal(got, ref)
     info = g.last()
     assert info["n_ranks"] == 1 and info["rank"] == 0 and info["transport"] == _abi.RT_TRANSPORT_NONE
     assert info["render_ms"] > 0 and info["bytes_sent"] == 0 and info["tiles_owned"] == -(-cfg.width // 48) * -(-cfg.height // 48)
@@ -697,6 +704,7 @@ def test_render_gather_device_single_rank_and_errors():
     h = C.c_void_p()
     assert lib.rt_comm_create(None, 2, 0, 0, C.byref(h)) == _abi.RT_ERR_INVALID_ARG  # id missing
     assert lib.rt_comm_create(None, 1, 1, 0, C.byref(h)) == _abi.RT_ERR_INVALID_ARG  # rank out of range
-    assert lib.rt_render_multi(None, 1, C.byref(p), fb.data_ptr(), None) == _abi.RT_ERR_INVALID_ARG
+    assert lib.rt_render_multi(None, 1, C.byref(p), got.ctypes.data, None) == _abi.RT_ERR_INVALID_ARG
     g.close()
     ds.close()
+    assert hip.hipFree(fb) == 0
