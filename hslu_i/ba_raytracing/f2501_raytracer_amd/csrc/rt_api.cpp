@@ -493,21 +493,29 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
 // 20-700 ns/ray instead of 7 (config 4: 1797 ms; 64 Mi-ray chunks: 452 ms).  The chunk is the whole
 // frame's primary rays when that fits: a queue level costs 2 * chunk * 48 B, and all levels together are
 // kept under RT_QUEUE_BUDGET -- this is what 288 GB of HBM are for.  RT_CHUNK_LOG2 overrides.
-static const size_t RT_QUEUE_BUDGET = (size_t)96 << 30;
-// log2 of the chunk: the frame's primary work items if the queues of all levels fit the budget -- at most
-// RT_QUEUE_BUDGET and at most 60 % of the HBM that is free now plus what the scene's queues already hold (a
-// shared or partitioned device renders with smaller chunks instead of failing).  tuning.chunk_log2 overrides.
-static int choose_chunk_log2(uint64_t primary_items, uint32_t levels, size_t queues_held, uint32_t forced) {
-  if (forced) return (int)forced;
+static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;
+// Rays per primary batch / secondary launch.  The whole frame's primary work items if the queues of all levels fit the
+// budget -- at most RT_QUEUE_BUDGET and at most 60 % of the HBM that is free now plus what the scene's queues already
+// hold (a shared or partitioned device renders with smaller chunks instead of failing); otherwise the frame is cut into
+// EQUAL batches (a small last batch would pay the full chain of per-level launch floors for few rays: config 5 spent
+// 20 % of its frame on the last 13 % of its pixels).  tuning.chunk_log2 overrides.  `shrink` halves the result (OOM retry).
+static uint32_t choose_chunk(uint64_t primary_items, uint32_t levels, size_t queues_held, uint32_t forced, uint32_t shrink) {
+  if (forced) return 1u << forced;
   size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     const size_t avail = (size_t)((double)(free_b + queues_held) * 0.6);
     if (avail < budget) budget = avail;
   }
-  int lg = 16;
-  while (lg < 26 && (1ull << lg) < primary_items) lg++;
-  while (lg > 16 && (size_t)levels * 2u * ((size_t)1 << lg) * 48u > budget) lg--;
-  return lg;
+  uint64_t max_chunk = budget / ((uint64_t)levels * 2u * 48u);
+  max_chunk >>= shrink;
+  if (max_chunk > (1ull << 28)) max_chunk = 1ull << 28;  // 32-bit ray indices, 2 x chunk per queue
+  if (max_chunk < (1ull << 16)) max_chunk = 1ull << 16;
+  const uint64_t items = primary_items ? primary_items : 1u;
+  const uint64_t n_batches = (items + max_chunk - 1) / max_chunk;
+  uint64_t chunk = (items + n_batches - 1) / n_batches;
+  chunk = (chunk + 255u) / 256u * 256u;  // whole workgroups
+  if (chunk < (1u << 10)) chunk = 1u << 10;
+  return (uint32_t)chunk;
 }
 #define RT_CHUNK (s->chunk)
 #define RT_QUEUE_CAP (2u * s->chunk)
@@ -584,14 +592,12 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->acc_pixels = npix;
   }
   // queues: one per tree level, 2 x chunk rays each; on out-of-memory retry with half the chunk
-  int lg = choose_chunk_log2((uint64_t)total_wgs * 256u, levels, s->queues.cap, forced_chunk_log2);
-  for (;;) {
-    s->chunk = 1u << lg;
+  for (uint32_t shrink = 0;; shrink++) {
+    s->chunk = choose_chunk((uint64_t)total_wgs * 256u, levels, s->queues.cap, forced_chunk_log2, shrink);
     rc = s->queues.ensure((size_t)levels * RT_QUEUE_PLANES * RT_QUEUE_CAP * sizeof(float4));
     if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4);
     if (rc == RT_OK) break;
-    if (rc != RT_ERR_OOM || forced_chunk_log2 || lg <= 16) return rc;
-    lg--;
+    if (rc != RT_ERR_OOM || forced_chunk_log2 || shrink >= 12) return rc;
   }
   if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
   HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));

@@ -63,7 +63,7 @@ if "GRBM_GUI_ACTIVE" in pmc:
     cycles = pmc["GRBM_GUI_ACTIVE"] / 8
     out.append(f"* effective clock {cycles / (frame_ms * 1e-3) / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)")
     if "SQ_INSTS_VALU" in pmc:
-        trans = pmc.get("SQ_INSTS_VALU_TRANS", 0.0)
+        trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
         issue = (pmc["SQ_INSTS_VALU"] - trans) * 2 + trans * 4
         out.append(f"* VALU-issue fraction = (SQ_INSTS_VALU x 2 cyc" + (f", {trans:.3g} transcendentals x 4 cyc" if trans else "")
                    + f") / (1024 SIMDs x {cycles:.4g} cycles) = {100 * issue / (1024 * cycles):.1f} %  (SIMD-32: a wave64 VALU instruction issues over 2 cycles)")
