@@ -64,6 +64,7 @@ class RenderConfig:
     cloud_seed: int = 1
     aa_seed: int = 1
     n_cloud_sets: int = 1024
+    scene_scale: float = 1.0  # SCENE_WIDTH (lib.rs:73 fixes it to 1.0): tests render scaled copies of a scene
 
     @staticmethod
     def from_features(features: Iterable[str] = (), **kw) -> "RenderConfig":
@@ -92,7 +93,7 @@ class RenderConfig:
 
     @property
     def scene_width(self) -> np.float32:
-        return F(1.0)
+        return F(self.scene_scale)
 
     @property
     def scene_height(self) -> np.float32:

@@ -219,7 +219,14 @@ typedef struct {
   float* lcol; /* [n][3] */
   float* lint; /* [n] */
   uint64_t rays[3], shadow;
+  uint32_t literal; /* RT_SIMD_LITERAL_*: reproduce packet-coupled behaviours of the reference (rt_simd_render_ex) */
 } ctx8;
+
+/* Packet-literal modes: the two places where the reference's result depends on WHICH rays share an 8-lane packet.
+ * The parity oracle and the GPU path decide them per lane / per pixel (deviations D3, D4 of DESIGN.md); these modes
+ * exist to measure how much that changes an image (tests/test_simd_baseline.py). */
+#define RT_SIMD_LITERAL_D3 1u /* refraction depth step / factor from the packet's horizontal max opacity, :458-491 */
+#define RT_SIMD_LITERAL_D4 2u /* without anti-aliasing one light cloud per 8-pixel packet, :1256-1280 */
 
 enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
 
@@ -465,8 +472,16 @@ static v8 refraction8(ctx8* c, const hit8* h, v8 view, f8 n_start, __m256i depth
   f8 sq = add8(mul8(inv_eta, ndi), _mm256_sqrt_ps(k));
   v8 q0 = vsub8(vscale8(view, inv_eta), vscale8(nn, sq));
   v8 q = vnormalize8(vsel8(kneg, vsplat(0, 0, 0), q0));
-  /* depth step / factor from the lane's own opacity (deviation D3) */
-  f8 lt05 = _mm256_cmp_ps(h->m.opacity, S8(0.5f), _CMP_LT_OQ), le03 = _mm256_cmp_ps(h->m.opacity, S8(0.3f), _CMP_LE_OQ);
+  /* depth step / factor from the lane's own opacity (deviation D3), or -- packet-literal mode -- from the horizontal
+   * max over the packet of opacity().simd_unwrap_or(0) (:458-463; non-transmissive and idle lanes count as 0) */
+  f8 op_eff = h->m.opacity;
+  if (c->literal & RT_SIMD_LITERAL_D3) {
+    float ops[8], mx = 0.0f;
+    _mm256_storeu_ps(ops, and8(h->m.opacity, and8(h->m.transmissive, h->valid)));
+    for (int l = 0; l < 8; l++) mx = ops[l] > mx ? ops[l] : mx;
+    op_eff = S8(mx);
+  }
+  f8 lt05 = _mm256_cmp_ps(op_eff, S8(0.5f), _CMP_LT_OQ), le03 = _mm256_cmp_ps(op_eff, S8(0.3f), _CMP_LE_OQ);
   const __m256i zero = _mm256_setzero_si256();
   __m256i step = sel8i(lt05, _mm256_set1_epi32(2), _mm256_set1_epi32(1));
   const int md = (int)P->max_depth_refraction;
@@ -559,6 +574,7 @@ typedef struct {
   uint32_t x0, y0, w, h, tiles_x, n_tiles;
   volatile uint32_t* next_tile;
   uint64_t rays[3], shadow, written;
+  uint32_t literal;
 } job8;
 
 static void write_pixel(job8* j, uint32_t pix, int any, float r, float g, float b, int id0, float t0) {
@@ -640,7 +656,10 @@ static void render_row(ctx8* c, job8* j, uint32_t gy, uint32_t gx0, uint32_t gx1
       n_live += on;
     }
     if (!n_live) continue;
-    for (int l = 0; l < 8; l++) build_lights8(c, pixs[l], l);
+    if (c->literal & RT_SIMD_LITERAL_D4)
+      build_lights8(c, gy * P->width + gx, -1); /* one cloud for the packet (here: its first pixel's set) */
+    else
+      for (int l = 0; l < 8; l++) build_lights8(c, pixs[l], l);
     v8 coords = V8(_mm256_loadu_ps(ox), _mm256_loadu_ps(oy), S8(0.0f));
     f8 act = _mm256_castsi256_ps(_mm256_loadu_si256((const __m256i*)live));
     trace8_t r = trace8(c, coords, vsub8(coords, focus), S8(P->air_ior), none, KIND_PRIMARY, act);
@@ -661,6 +680,7 @@ static void* worker8(void* arg) {
   c.s = j->s;
   c.p = j->p;
   c.cull = (j->p->flags & RT_FLAG_BACKFACE_CULLING) != 0;
+  c.literal = j->literal;
   const uint32_t N = j->p->light_mult < 1 ? 1 : j->p->light_mult;
   const size_t nl = (size_t)j->s->n_lights * N + 1;
   c.lpos = (float*)aligned_alloc(32, sizeof(float) * 24 * nl);
@@ -689,8 +709,15 @@ static void* worker8(void* arg) {
 
 /* Same contract as rt_render (include/rt_hip.h), computed on the host with 8-lane packets over 48x48 tiles.
  * n_threads <= 0 -> 1.  The tile grid starts at the window's corner (image_buffer.rs:48-97 tiles the whole buffer). */
+int rt_simd_render_ex(const rt_scene_desc* desc, const rt_params* params, uint32_t* argb, const rt_aux* aux, rt_stats* stats,
+                      int n_threads, uint32_t literal);
 int rt_simd_render(const rt_scene_desc* desc, const rt_params* params, uint32_t* argb, const rt_aux* aux, rt_stats* stats,
                    int n_threads) {
+  return rt_simd_render_ex(desc, params, argb, aux, stats, n_threads, 0u);
+}
+/* literal: RT_SIMD_LITERAL_* bits (0 = the parity oracle's per-lane / per-pixel decisions) */
+int rt_simd_render_ex(const rt_scene_desc* desc, const rt_params* params, uint32_t* argb, const rt_aux* aux, rt_stats* stats,
+                      int n_threads, uint32_t literal) {
   if (!desc || !params || !argb) return RT_ERR_INVALID_ARG;
   if (desc->abi_version != RT_ABI_VERSION || params->abi_version != RT_ABI_VERSION) return RT_ERR_INVALID_ARG;
   if (params->light_mult > 1 && (params->n_cloud_sets == 0 || !params->cloud_sets)) return RT_ERR_INVALID_ARG;
@@ -713,6 +740,7 @@ int rt_simd_render(const rt_scene_desc* desc, const rt_params* params, uint32_t*
     jobs[i].x0 = x0, jobs[i].y0 = y0, jobs[i].w = w, jobs[i].h = h;
     jobs[i].tiles_x = tiles_x, jobs[i].n_tiles = tiles_x * tiles_y;
     jobs[i].next_tile = &next_tile;
+    jobs[i].literal = literal;
   }
   if (n_threads == 1) {
     worker8(&jobs[0]);

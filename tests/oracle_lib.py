@@ -36,6 +36,8 @@ def load():
                                   C.POINTER(_abi.rt_aux), C.POINTER(_abi.rt_stats), C.c_int]
     lib.rt_simd_render.restype = C.c_int
     lib.rt_simd_render.argtypes = lib.rt_cpu_render.argtypes
+    lib.rt_simd_render_ex.restype = C.c_int
+    lib.rt_simd_render_ex.argtypes = lib.rt_cpu_render.argtypes + [C.c_uint32]
     fp = C.POINTER(C.c_float)
     lib.rt_oracle_sphere.restype = C.c_int
     lib.rt_oracle_sphere.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_uint32, fp, fp, C.c_int, fp]
@@ -66,7 +68,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, aa_offsets=None, cloud=None, impl="scalar"):
+LITERAL_D3, LITERAL_D4 = 1, 2  # rt_simd_baseline.c: packet-literal modes
+
+
+def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, aa_offsets=None, cloud=None, impl="scalar",
+           literal=0):
     """Brute-force CPU render of `window` (x0,y0,w,h) of the frame.  impl: "scalar" = the parity oracle
     (rt_oracle.c), "simd" = the 8-lane AVX2 packet baseline over 48x48 tiles (rt_simd_baseline.c).
     Returns (argb, planes, stats)."""
@@ -81,8 +87,13 @@ def render(flat, cfg, window=None, n_ranks=1, rank=0, n_threads=None, aux=True, 
     st = _abi.rt_stats()
     if n_threads is None:
         n_threads = min(host_cores(), 16)
-    fn = lib.rt_simd_render if impl == "simd" else lib.rt_cpu_render
-    rc = fn(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st), int(n_threads))
+    if literal:
+        assert impl == "simd", "packet-literal modes exist only in the packet implementation"
+        rc = lib.rt_simd_render_ex(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st),
+                                   int(n_threads), int(literal))
+    else:
+        fn = lib.rt_simd_render if impl == "simd" else lib.rt_cpu_render
+        rc = fn(C.byref(desc), C.byref(p), argb.ctypes.data, C.byref(a) if aux else None, C.byref(st), int(n_threads))
     if rc != 0:
         raise RuntimeError(f"rt_cpu_render failed: {rc}")
     return argb, planes, st.as_dict()

@@ -274,12 +274,13 @@ def test_window_smaller_than_a_tile_and_single_pixel():
 
 def random_scene(seed, n_spheres, n_tris, n_lights, cfg):
     """Seeded random soup: spheres and triangles of mixed sizes (incl. slivers and near-degenerate ones),
-    diffuse / metallic / transmissive materials, lights inside the view volume."""
+    diffuse / metallic / transmissive materials, lights inside the view volume.  Geometry scales with
+    cfg.scene_scale (the same soup, 100x larger or smaller)."""
     from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import FlatScene
     rng = np.random.default_rng(seed)
     f32 = np.float32
-    sh = float(cfg.scene_height)
-    sd = float(cfg.scene_depth)
+    sh = float(cfg.scene_height) / float(cfg.scene_scale)  # the soup is drawn for a width-1 scene and scaled at the end
+    sd = float(cfg.scene_depth) / float(cfg.scene_scale)
     mats = []
     for _ in range(12):
         kind = rng.integers(0, 4)
@@ -312,8 +313,12 @@ def random_scene(seed, n_spheres, n_tris, n_lights, cfg):
     lights[:, :3] = rng.uniform([0.1, 0.05, 0.0], [0.9, sh * 0.6, sd * 0.5], (n_lights, 3))
     lights[:, 3:6] = rng.uniform(0.4, 1.0, (n_lights, 3))
     lights[:, 6] = rng.uniform(0.2, 0.8, n_lights)
-    return FlatScene(sc, (sr * sr).astype(f32), (1 / sr).astype(f32), rng.integers(0, len(mats), n_spheres).astype(np.uint32),
-                     v1, e1, e2, nrm, rng.integers(0, len(mats), n_tris).astype(np.uint32), mats, lights)
+    sm, tm = rng.integers(0, len(mats), n_spheres).astype(np.uint32), rng.integers(0, len(mats), n_tris).astype(np.uint32)
+    k = f32(cfg.scene_scale)
+    if k != 1:
+        sc, v1, sr, e1, e2 = sc * k, v1 * k, sr * k, e1 * k, e2 * k
+        lights[:, :3] *= k
+    return FlatScene(sc, (sr * sr).astype(f32), (1 / sr).astype(f32), sm, v1, e1, e2, nrm, tm, mats, lights)
 
 
 @pytest.mark.parametrize("seed", list(range(1, 11)))
@@ -323,6 +328,19 @@ def test_random_scenes_all_features(seed):
     oracle on random geometry with all features on."""
     cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160,
                                      height_override=128, n_cloud_sets=16, depth_override=3, cloud_seed=seed)
+    flat = random_scene(seed, n_spheres=6 + seed, n_tris=300 + 100 * seed, n_lights=3, cfg=cfg)
+    compare(cfg, flat, ((13 * seed) % 100, (7 * seed) % 80, 56, 40))
+
+
+@pytest.mark.parametrize("scale", [100.0, 0.01])
+@pytest.mark.parametrize("seed", [3, 8])
+def test_random_scenes_scaled_and_translated(scale, seed):
+    """The conservative margins of the kernel (padded boxes, slab slack, pre-filter, beam and umbra tests) mix relative
+    and absolute terms; the two named scenes live in [0, 1]^3.  The same random soup 100x larger and 100x smaller
+    (camera, pixel factors, light clouds and eps_distance scale along, as lib.rs derives them from SCENE_WIDTH) must
+    still agree with the brute-force oracle."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160, height_override=128,
+                                     n_cloud_sets=16, depth_override=3, cloud_seed=seed, scene_scale=scale)
     flat = random_scene(seed, n_spheres=6 + seed, n_tris=300 + 100 * seed, n_lights=3, cfg=cfg)
     compare(cfg, flat, ((13 * seed) % 100, (7 * seed) % 80, 56, 40))
 
@@ -708,3 +726,53 @@ def test_render_gather_device_single_rank_and_errors():
     g.close()
     ds.close()
     assert hip.hipFree(fb) == 0
+
+
+# regions of the reference's output.png (1140x950), in 4x4-box coordinates (285x237): (x0, y0, x1, y1) or a disc
+OUTPUT_PNG_REGIONS = {
+    "glass sphere (refraction + Fresnel + absorption)": ("disc", 137, 98, 48),
+    "text left of the sphere": ("rect", 44, 58, 84, 124),
+    "text seen through the sphere": ("rect", 112, 62, 162, 118),
+    "back wall, lit": ("rect", 14, 28, 60, 56),
+    "back wall, text shadows": ("rect", 18, 92, 44, 128),
+    "right wall": ("rect", 214, 40, 268, 150),
+    "floor slab and its shadows": ("rect", 50, 204, 240, 226),
+    "pile of metallic glass spheres (deep ray trees)": ("rect", 176, 146, 238, 192),
+    "opaque / metallic spheres": ("rect", 26, 138, 164, 204),
+}
+
+
+def test_default_features_match_reference_output_png_by_region():
+    """The only reference-held result, region by region: a wrong Fresnel / absorption / attenuation / shadow term moves
+    the mean or the contrast of the region it acts on, which one global PSNR cannot see.  Bounds: per-channel mean
+    within 2.5/255, contrast (std of the luma) within 12 %, mean absolute difference of the 4x4-box pixels within the
+    noise of the stochastic reference (unseeded AA table and light clouds)."""
+    from PIL import Image
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.config import DEFAULT_FEATURES
+    cfg = RenderConfig.from_features(DEFAULT_FEATURES)
+    buf = ImageBuffer.new(cfg.width, cfg.height)
+    RaytracerRenderer(cfg).render(buf, scenes.semesterbild(cfg))
+    img = buf.as_rgb8().astype(np.float32)
+    h4, w4 = cfg.height // 4 * 4, cfg.width // 4 * 4
+    box = img[:h4, :w4].reshape(h4 // 4, 4, w4 // 4, 4, 3).mean(axis=(1, 3))
+    ref = np.asarray(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                             "reference_output_box4.png")).convert("RGB")).astype(np.float32)
+    yy, xx = np.mgrid[0:box.shape[0], 0:box.shape[1]]
+    worst = []
+    for name, spec in OUTPUT_PNG_REGIONS.items():
+        if spec[0] == "disc":
+            m = (xx - spec[1]) ** 2 + (yy - spec[2]) ** 2 <= spec[3] ** 2
+        else:
+            m = (xx >= spec[1]) & (xx < spec[3]) & (yy >= spec[2]) & (yy < spec[4])
+        a, b = box[m], ref[m]
+        dmean = np.abs(a.mean(axis=0) - b.mean(axis=0))
+        luma = lambda v: v @ np.asarray([0.2126, 0.7152, 0.0722], np.float32)
+        sa, sb = float(luma(a).std()), float(luma(b).std())
+        mae = float(np.abs(a - b).mean())
+        print(f"{name:52s} n={int(m.sum()):5d} mean ours {a.mean(axis=0).round(1)} ref {b.mean(axis=0).round(1)} |d| {dmean.round(2)} "
+              f"std {sa:.2f} vs {sb:.2f}  MAE {mae:.2f}")
+        worst.append((name, float(dmean.max()), abs(sa / max(sb, 1e-6) - 1.0), mae))
+    for name, dm, ds, mae in worst:
+        assert dm <= 2.5, (name, "mean", dm)
+        assert ds <= 0.12, (name, "contrast", ds)
+        assert mae <= 3.0, (name, "MAE", mae)

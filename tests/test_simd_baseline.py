@@ -47,3 +47,63 @@ def test_packets_equal_scalar_oracle_on_semesterbild_and_tile_ownership():
     flat1 = scenes.test_scene(cfg1).flatten()
     for rank in range(3):
         assert_same(*both(cfg1, flat1, None, n_ranks=3, rank=rank))
+
+
+def _diff(a, b, win, cfg):
+    (argb_a, pa, _), (argb_b, pb, _) = a, b
+    m = np.zeros((cfg.height, cfg.width), bool)
+    m[win[1]:win[1] + win[3], win[0]:win[0] + win[2]] = True
+    m = m.ravel()
+    d = np.abs(pa["rgb"][m] - pb["rgb"][m]).max(axis=1)
+    return int((d > 1e-4).sum()), float(d.max()), int((argb_a[m] != argb_b[m]).sum()), int(m.sum())
+
+
+def test_size_of_the_packet_coupled_deviations_d3_d4():
+    """DESIGN.md deviations D3 / D4 quantified with the packet-literal modes of the 8-lane baseline:
+    D3 (refraction depth step from the packet's horizontal max opacity, raytracer_renderer.rs:458-491) changes NOTHING
+    on the two named scenes (every transmissive material has opacity >= 0.6), and only shortens ray trees on a
+    synthetic variant with opacities below 0.5; D4 (one light cloud per 8-pixel packet without anti-aliasing,
+    :1256-1280) moves soft-shadow penumbrae by the sampling noise of the cloud."""
+    import dataclasses
+    L3, L4 = oracle_lib.LITERAL_D3, oracle_lib.LITERAL_D4
+    # D3 on the named scenes: identical
+    cfg = RenderConfig.from_features(["reflections", "refractions"], depth_override=6)
+    flat = scenes.test_scene(cfg).flatten()
+    win = (280, 170, 96, 64)
+    base = oracle_lib.render(flat, cfg, window=win, n_threads=4, impl="simd")
+    lit = oracle_lib.render(flat, cfg, window=win, n_threads=4, impl="simd", literal=L3)
+    assert _diff(base, lit, win, cfg)[:3] == (0, 0.0, 0)
+    cfg_s = RenderConfig.from_features(["high_resolution", "realistic"], depth_override=8)
+    flat_s = scenes.semesterbild(cfg_s, "text_lowres").flatten()
+    win_s = (1230, 960, 32, 24)  # the pile of metallic glass spheres
+    base_s = oracle_lib.render(flat_s, cfg_s, window=win_s, n_threads=4, impl="simd")
+    lit_s = oracle_lib.render(flat_s, cfg_s, window=win_s, n_threads=4, impl="simd", literal=L3)
+    assert _diff(base_s, lit_s, win_s, cfg_s)[:3] == (0, 0.0, 0)
+    assert base_s[2]["rays_refraction"] == lit_s[2]["rays_refraction"] > 0
+    # D3 where it can matter: transmissive opacities on both sides of the 0.3 / 0.5 thresholds (0.25 .. 0.75), whole frame.
+    # Only packets that straddle two objects with different opacities decide differently: silhouette pixels.
+    cfg_m = RenderConfig.from_features(["reflections", "refractions"], depth_override=6, width_override=384, height_override=320)
+    flat_m = scenes.test_scene(cfg_m).flatten()
+    mats = flat_m.materials.copy()
+    tr = mats[:, 8] != 0
+    vals = np.linspace(0.25, 0.75, int(tr.sum())).astype(np.float32)
+    np.random.default_rng(1).shuffle(vals)
+    mats[tr, 6] = vals
+    flat_lo = dataclasses.replace(flat_m, materials=mats)
+    full = (0, 0, cfg_m.width, cfg_m.height)
+    base_lo = oracle_lib.render(flat_lo, cfg_m, n_threads=4, impl="simd")
+    lit_lo = oracle_lib.render(flat_lo, cfg_m, n_threads=4, impl="simd", literal=L3)
+    n_bad, dmax, n_px, n_all = _diff(base_lo, lit_lo, full, cfg_m)
+    print(f"D3, opacities 0.25-0.75: {n_bad}/{n_all} pixels beyond 1e-4 (max |dRGB| {dmax:.3f}), {n_px} packed pixels differ; "
+          f"refraction rays {base_lo[2]['rays_refraction']} per-lane vs {lit_lo[2]['rays_refraction']} packet-literal")
+    assert 0 < n_bad < 0.01 * n_all
+    # D4: soft shadows without anti-aliasing
+    cfg4 = RenderConfig.from_features(["soft_shadows"], n_cloud_sets=64)
+    flat4 = scenes.test_scene(cfg4).flatten()
+    win4 = (300, 380, 160, 64)  # floor with penumbrae
+    base4 = oracle_lib.render(flat4, cfg4, window=win4, n_threads=4, impl="simd")
+    lit4 = oracle_lib.render(flat4, cfg4, window=win4, n_threads=4, impl="simd", literal=L4)
+    n_bad, dmax, n_px, n_all = _diff(base4, lit4, win4, cfg4)
+    print(f"D4, test_scene soft shadows no AA: {n_bad}/{n_all} pixels beyond 1e-4 (max |dRGB| {dmax:.3f}), mean |dRGB| "
+          f"{float(np.abs(base4[1]['rgb'] - lit4[1]['rgb']).sum() / (3 * n_all)):.5f}")
+    assert dmax < 0.25 and np.array_equal(base4[1]["hit_id"], lit4[1]["hit_id"])
