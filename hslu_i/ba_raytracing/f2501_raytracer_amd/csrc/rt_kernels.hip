@@ -1692,12 +1692,17 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   wave_flush(wv, P, (uint32_t)__popcll(wave_ballot(wrote)), lds_cnt);
 }
 
-// __launch_bounds__(256, 4): 127 VGPRs, NO scratch.  Measured on MI355X, config 3 (this kernel):
-// 4 waves/SIMD, no spills 37.7 ms | 5 waves, 144 B/lane scratch 35.3 ms | 6 waves, 220 B/lane 37.5 ms.
-// The 6 % of the 5-wave build is bought with ~40 GB of scratch traffic per frame through HBM
-// (rocprofv3 FETCH_SIZE/WRITE_SIZE: 1 TB/s, against 2.2 GB of algorithmic ray bytes); the spill-free
-// build keeps the kernel's HBM traffic at the framebuffer + scene level.
-__global__ __launch_bounds__(256, 4) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
+// Occupancy.  The kernel is LATENCY bound: a wavefront issues one instruction every ~12 cycles (dependent scalar-load ->
+// vote -> branch chains of the wave-cooperative walks), so the SIMDs are fed by the number of resident waves.
+// Round 1 (much more work per wave) preferred 4 waves / 108 VGPRs without scratch; measured on MI355X on this build:
+//   waves/SIMD (VGPRs, scratch B/lane):  4 (108, 0)   5 (96, 60)   6 (80, 132)   7 (72, 168)   8 (64, 216)
+//   config 3, ms                          7.66         6.91         6.42          7.40          8.82
+//   config 4, ms                          80.2         75.9         74.0          77.9          88.1
+// The 6-wave spills sit outside the innermost loops; scratch traffic stays in L2 / Infinity Cache.
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 6
+#endif
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
@@ -1829,7 +1834,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
-__global__ __launch_bounds__(256, 4) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)

@@ -744,9 +744,10 @@ OUTPUT_PNG_REGIONS = {
 
 def test_default_features_match_reference_output_png_by_region():
     """The only reference-held result, region by region: a wrong Fresnel / absorption / attenuation / shadow term moves
-    the mean or the contrast of the region it acts on, which one global PSNR cannot see.  Bounds: per-channel mean
-    within 2.5/255, contrast (std of the luma) within 12 %, mean absolute difference of the 4x4-box pixels within the
-    noise of the stochastic reference (unseeded AA table and light clouds)."""
+    the mean or the contrast of the region it acts on, which one global PSNR cannot see.  Bounds (2x what the current
+    build measures: means agree within 0.33/255, contrast within 0.5 %, MAE <= 0.94): per-channel mean within 0.75/255,
+    contrast (std of the luma) within 2 %, mean absolute difference of the 4x4-box pixels <= 1.6/255 -- the noise of
+    the stochastic reference (unseeded AA table and light clouds)."""
     from PIL import Image
     from hslu_i.ba_raytracing.f2501_raytracer_amd.config import DEFAULT_FEATURES
     cfg = RenderConfig.from_features(DEFAULT_FEATURES)
@@ -773,6 +774,6 @@ def test_default_features_match_reference_output_png_by_region():
               f"std {sa:.2f} vs {sb:.2f}  MAE {mae:.2f}")
         worst.append((name, float(dmean.max()), abs(sa / max(sb, 1e-6) - 1.0), mae))
     for name, dm, ds, mae in worst:
-        assert dm <= 2.5, (name, "mean", dm)
-        assert ds <= 0.12, (name, "contrast", ds)
-        assert mae <= 3.0, (name, "MAE", mae)
+        assert dm <= 0.75, (name, "mean", dm)
+        assert ds <= 0.02, (name, "contrast", ds)
+        assert mae <= 1.6, (name, "MAE", mae)
