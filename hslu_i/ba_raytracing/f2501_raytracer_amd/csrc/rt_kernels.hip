@@ -110,6 +110,22 @@ __device__ __forceinline__ V3 normalize(V3 a) {
   float r = 1.0f / mag(a);
   return a * r;
 }
+// normalize() of a vector that is ALREADY unit up to rounding: a shadow ray's direction ld = ltp * (1 / |ltp|) is
+// normalised once more by Ray::new_with_mask (ray.rs:52-57).  s = |a|^2 then lies within a few ulp of 1, and there the
+// correctly rounded 1 / sqrt(s) -- an IEEE sqrt and an IEEE division, 57 + 44 SIMD cycles -- is a function of the
+// integer distance k of s from 1.0f:
+//   s = 1 + k ulp (k >= 0):   sqrt = 1 + floor(k/2) ulp  (kx/2 - k^2 x^2/8 lies just below the tie)  ->  r = 1 - floor(k/2) ulp
+//   s = 1 - j ulp/2 (j > 0):  sqrt = 1 - ceil(j/2) ulp/2,  n = ceil(j/2)                              ->  r = 1 + ceil(n/2) ulp
+// (exact for |k| < 2898; checked exhaustively on the host, tests/test_host_logic.py).  Lanes outside |k| <= 1024 (never a
+// unit vector; NaN / zero input) send the wavefront through the generic sequence.
+__device__ __forceinline__ V3 normalize_unit(V3 a, lanemask lanes) {
+  const float s = dot(a, a);
+  const int k = (int)__float_as_uint(s) - 0x3f800000;
+  if (wave_ballot((uint32_t)(k + 1024) > 2048u) & lanes) return normalize(a);
+  const int q = ((((-k) + 1) >> 1) + 1) >> 1;
+  const uint32_t rb = k >= 0 ? 0x3f800000u - (uint32_t)((k >> 1) * 2) : 0x3f800000u + (uint32_t)q;
+  return a * __uint_as_float(rb);
+}
 __device__ __forceinline__ V3 fma_s(V3 d, float t, V3 o) {
   return mk(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z));
 }
@@ -872,7 +888,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   S.occ = 0ull;
   S.opacity = 1.0f;
   S.filter = mk(1.0f, 1.0f, 1.0f);
-  V3 d = normalize(d_raw);  // Ray::new_with_mask re-normalises, ray.rs:52-57
+  V3 d = normalize_unit(d_raw, grp);  // Ray::new_with_mask re-normalises, ray.rs:52-57 (d_raw is unit up to rounding)
 #if RT_PROFILE
   RT_OPAQUE(d.x);
   PROF_ADD(W, 2, W.t_mark);

@@ -237,3 +237,18 @@ def test_output_encoder_matches_oracle_pack(oracle, tmp_path):
     FileOutput.new(path).render_buffer(buf)
     img = np.asarray(Image.open(path))
     assert img.shape == (2, 4, 3) and img[0, 0].tolist() == [255, 0, 0] and img[1, 0].tolist() == [0x10, 0x20, 0x30]
+
+
+def test_exact_reciprocal_sqrt_near_one():
+    """csrc/rt_kernels.hip normalize_unit: for s within 1024 ulp of 1.0f the correctly rounded 1 / sqrt(s) (IEEE sqrt, then
+    IEEE division -- what normalize() computes and the oracle's vnormalize does) is a closed form of the integer
+    distance of s from 1.0f.  Exhaustive over the range the kernel uses (and exact well beyond it)."""
+    one = int(np.float32(1.0).view(np.uint32))
+    for k in range(-2800, 2801):
+        s = np.uint32(one + k).view(np.float32)
+        ref = int((np.float32(1.0) / np.sqrt(s)).view(np.uint32))
+        if k >= 0:
+            rb = 0x3F800000 - (k >> 1) * 2
+        else:
+            rb = 0x3F800000 + (((((-k) + 1) >> 1) + 1) >> 1)
+        assert ref == rb, (k, hex(ref), hex(rb))
