@@ -48,7 +48,7 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
-  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->fb, &s->aux_rgb,
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb,
                     &s->aux_id, &s->aux_t})
     b->release();
   delete s;
@@ -219,6 +219,34 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
           oct[o * nn + i] = d0;
         }
       put(&s->dev.off_nodes_oct, oct.data(), oct.size() * sizeof(RtNode));
+    }
+    {
+      // threaded copy (depth first, skip links) for the stackless per-lane walk of incoherent wavefronts
+      std::vector<RtThrNode> thr;
+      struct Emit {
+        const std::vector<RtNode>& nodes;
+        std::vector<RtThrNode>& out;
+        void child(const float* lo, const float* hi, uint32_t c, uint32_t n) {
+          if (c == RT_NODE_EMPTY) return;
+          const size_t idx = out.size();
+          RtThrNode t;
+          memcpy(t.lo, lo, 12), memcpy(t.hi, hi, 12);
+          t.skip = 0;
+          t.leaf = n ? ((n << 24) | c) : 0u;
+          out.push_back(t);
+          if (!n) node(c);
+          out[idx].skip = (uint32_t)out.size();
+        }
+        void node(uint32_t i) {
+          const RtNode nd = nodes[i];
+          child(nd.lo0, nd.hi0, nd.c0, nd.n0);
+          child(nd.lo1, nd.hi1, nd.c1, nd.n1);
+        }
+      } emit{bvh.nodes, thr};
+      if (!bvh.nodes.empty()) emit.node(0);
+      if (n_slots >= (1u << 24)) return bail(fail(RT_ERR_UNSUPPORTED, "more than 2^24 triangle references"));
+      s->dev.n_thr = (uint32_t)thr.size();
+      put(&s->dev.off_nodes_thr, thr.data(), thr.size() * sizeof(RtThrNode));
     }
   }
   {
@@ -499,14 +527,14 @@ static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;
 // hold (a shared or partitioned device renders with smaller chunks instead of failing); otherwise the frame is cut into
 // EQUAL batches (a small last batch would pay the full chain of per-level launch floors for few rays: config 5 spent
 // 20 % of its frame on the last 13 % of its pixels).  tuning.chunk_log2 overrides.  `shrink` halves the result (OOM retry).
-static uint32_t choose_chunk(uint64_t primary_items, uint32_t levels, size_t queues_held, uint32_t forced, uint32_t shrink) {
+static uint32_t choose_chunk(uint64_t primary_items, size_t bytes_per_item, size_t queues_held, uint32_t forced, uint32_t shrink) {
   if (forced) return 1u << forced;
   size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     const size_t avail = (size_t)((double)(free_b + queues_held) * 0.6);
     if (avail < budget) budget = avail;
   }
-  uint64_t max_chunk = budget / ((uint64_t)levels * 2u * 48u);
+  uint64_t max_chunk = budget / bytes_per_item;
   max_chunk >>= shrink;
   if (max_chunk > (1ull << 28)) max_chunk = 1ull << 28;  // 32-bit ray indices, 2 x chunk per queue
   if (max_chunk < (1ull << 16)) max_chunk = 1ull << 16;
@@ -520,11 +548,29 @@ static uint32_t choose_chunk(uint64_t primary_items, uint32_t levels, size_t que
 #define RT_CHUNK (s->chunk)
 #define RT_QUEUE_CAP (2u * s->chunk)
 
-static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels, hipStream_t stream) {
-  uint32_t n = 0;
+// Reads the queue counters (one small copy + one synchronisation) and traces the "hard" pairs the launch before
+// deferred (rt_hard_kernel), so that the hard queue is empty again before the next producer runs.
+static int sync_counts(rt_scene* s, RtDevParams& P, uint32_t levels, hipStream_t stream, uint32_t* host) {
   uint32_t* counts = (uint32_t*)s->qcount.p;
-  HIP_TRY(hipMemcpyAsync(&n, counts + k, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(host, counts, (size_t)(levels + 4) * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  const uint32_t nh = host[levels + 2];
+  if (nh && P.hard_q) {
+    if (nh > P.hard_capacity) return fail(RT_ERR_HIP, "hard-pair queue overflowed (%u pairs)", nh);
+    P.hard_in_count = nh;
+    hipError_t e = (hipError_t)rt_launch_hard(s->dev, P, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "hard-pair launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(counts + levels + 2, 0, 4, stream));
+  }
+  return RT_OK;
+}
+
+static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels, hipStream_t stream) {
+  uint32_t host[64 + 4];
+  uint32_t* counts = (uint32_t*)s->qcount.p;
+  int rc0 = sync_counts(s, P, levels, stream, host);
+  if (rc0 != RT_OK) return rc0;
+  const uint32_t n = host[k];
   if (n == 0) return RT_OK;
   if (n > RT_QUEUE_CAP) return fail(RT_ERR_HIP, "ray queue %u overflowed (%u rays)", k, n);
   float4* qbase = (float4*)s->queues.p;
@@ -554,6 +600,9 @@ static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels,
     if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
     if (k < levels) {
       int rc = drain_level(s, P, k + 1, levels, stream);
+      if (rc != RT_OK) return rc;
+    } else if (P.hard_q) {
+      int rc = sync_counts(s, P, levels, stream, host);  // pairs deferred by the last level's shading
       if (rc != RT_OK) return rc;
     }
   }
@@ -592,13 +641,20 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->acc_pixels = npix;
   }
   // queues: one per tree level, 2 x chunk rays each; on out-of-memory retry with half the chunk
+  // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs; the queue is
+  // sized for the worst case of one launch (every ray x every light: 64 B each), so a push can never fail.
+  const bool hard = P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
+  const size_t bytes_per_item = (size_t)levels * 2u * 48u + 24u + (hard ? (size_t)s->dev.n_lights * 64u : 0u);
   for (uint32_t shrink = 0;; shrink++) {
-    s->chunk = choose_chunk((uint64_t)total_wgs * 256u, levels, s->queues.cap, forced_chunk_log2, shrink);
+    s->chunk = choose_chunk((uint64_t)total_wgs * 256u, bytes_per_item, s->queues.cap + s->hard.cap, forced_chunk_log2, shrink);
     rc = s->queues.ensure((size_t)levels * RT_QUEUE_PLANES * RT_QUEUE_CAP * sizeof(float4));
     if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4);
+    if (rc == RT_OK && hard) rc = s->hard.ensure(((size_t)RT_CHUNK * s->dev.n_lights + 64u) * 4u * sizeof(float4));
     if (rc == RT_OK) break;
     if (rc != RT_ERR_OOM || forced_chunk_log2 || shrink >= 12) return rc;
   }
+  P.hard_q = hard ? (float4*)s->hard.p : nullptr;
+  P.hard_capacity = hard ? RT_CHUNK * s->dev.n_lights : 0u;
   if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
   HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));
   uint32_t* counts = (uint32_t*)s->qcount.p;  // [0] = overflow flag, [k] = rays waiting at level k
@@ -618,6 +674,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   P.acc = (long long*)s->acc.p;
   P.q_capacity = RT_QUEUE_CAP;
   P.q_overflow = counts;
+  P.hard_count = counts + levels + 2;
   const uint32_t batch_wgs = RT_CHUNK / 256u;
   for (uint32_t w0 = 0; w0 < total_wgs; w0 += batch_wgs) {
     uint32_t n = (total_wgs - w0) < batch_wgs ? (total_wgs - w0) : batch_wgs;

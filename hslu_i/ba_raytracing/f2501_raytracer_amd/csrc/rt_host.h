@@ -59,7 +59,7 @@ struct rt_scene {
   rt_bvh_info info{};
   DevBuf blob;  // spheres, triangles, materials, lights, BVH (RtDevScene offsets)
   // per-render workspaces
-  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp;
+  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp, hard;
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use

@@ -34,6 +34,17 @@ struct RtNode {
 };
 static_assert(sizeof(RtNode) == 64, "node must be 64 bytes");
 
+// The same tree in depth-first order with skip links ("threaded"): one box per entry, `skip` = the entry to continue with
+// when the box is missed (or after a leaf), so a walk needs NO stack -- the per-lane (divergent) any-hit traversal of
+// incoherent wavefronts.  leaf = triangle count << 24 | first slot (0 = internal node: its children follow).
+struct RtThrNode {
+  float lo[3];
+  uint32_t skip;
+  float hi[3];
+  uint32_t leaf;
+};
+static_assert(sizeof(RtThrNode) == 32, "threaded node must be 32 bytes");
+
 #define RT_NODE_EMPTY 0xFFFFFFFFu  // c* value of an absent child (box is inverted, never hit)
 #define RT_TRI_DUPLICATE 0x80000000u  // tri_id flag: not the first reference of its triangle (slot order)
 #define RT_TRI_TRANSMISSIVE 0x40000000u  // tri_id flag (device copy): the triangle's material lets light through
@@ -68,6 +79,8 @@ struct RtDevScene {
   // 8 copies of nodes, one per direction octant o (bit a = direction negative along axis a): lo* hold the entry
   // planes and hi* the exit planes for that octant, children are in near-first order (octant o: [o * n_nodes ...])
   uint32_t off_nodes_oct;
+  uint32_t off_nodes_thr;   // RtThrNode[n_thr]: the tree threaded for stackless per-lane walks
+  uint32_t n_thr;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
   uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
 };
@@ -119,6 +132,14 @@ struct RtDevParams {
   const float4* q_in;     // secondary kernel: rays [q_in_first, q_in_first + q_in_count)
   uint32_t q_in_first, q_in_count;
   long long* acc;         // [W*H][4] fixed-point RGB accumulator + primary-hit flag (nullptr: direct write)
+  // "Hard" (hit point, light) pairs: soft-shadow sets of INCOHERENT wavefronts (their shared candidate list overflows)
+  // are not traced where they are found; every lane's pair is appended here and rt_hard_kernel traces it with the N
+  // samples of the pair spread over N lanes.  4 float4 planes of hard_capacity + 64 entries (the last 64: dump slots
+  // of idle lanes): {p, bits(material row)} {n, bits(light)} {view d, bits(pixel)} {W * atten, bits(multiplicity)}.
+  float4* hard_q;         // nullptr: no deferral (no accumulator to add to, or no soft shadows)
+  uint32_t* hard_count;
+  uint32_t hard_capacity;
+  uint32_t hard_in_count;  // rt_hard_kernel: pairs to trace
   uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
   // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;
   // nullptr = all super-tiles of the window
@@ -146,6 +167,7 @@ int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream);
 // rocPRIM radix sort of (key, value) pairs (rt_sort.hip); tmp == nullptr: only returns the temp size
 int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n,
                   void* tmp, size_t* tmp_bytes, void* stream);
+int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
 // multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame
 int rt_launch_scatter(uint32_t* argb, const uint32_t* recv, const uint32_t* rank_off, const uint32_t* tile_slot, uint32_t width,

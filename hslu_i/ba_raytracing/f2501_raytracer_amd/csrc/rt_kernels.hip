@@ -415,6 +415,20 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
   S.filter = mk(on ? nf.x : S.filter.x, on ? nf.y : S.filter.y, on ? nf.z : S.filter.z);
 }
 
+// same for an occluder whose material differs from lane to lane (per-lane walk, rt_hard_kernel)
+template <bool CULL>
+__device__ __forceinline__ void shadow_accumulate_lane(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
+  if (CULL) h &= wave_ballot(m.transmissive || dot(d, n) < 0.75f);  // sphere.rs:137-151, triangle.rs:154-168
+  const V3 refl = fresnel_reflectance(m, n, -d, 1.0f);
+  const float io = m.transmissive ? m.opacity * (1.0f - refl.x) : 0.0f;
+  const bool on = lane_of(h);
+  const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
+  S.opacity = on ? nop : S.opacity;
+  S.occ |= h & wave_ballot(!m.transmissive && fabsf(nop - 0.0f) <= RT_EPS);
+  const V3 nf = S.filter - absorption(m);
+  S.filter = mk(on ? nf.x : S.filter.x, on ? nf.y : S.filter.y, on ? nf.z : S.filter.z);
+}
+
 struct WaveCtx {
   // wave-level work counters (uniform)
   uint32_t n_nodes, n_tris, s_nodes, s_tris, s_passes, n_exact, s_exact;  // one ray per wavefront: 32 bits are plenty
@@ -1154,12 +1168,33 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
   }
 }
 
+// appends the (hit point, light) pairs of the lanes in `m` to the hard queue (see RtDevParams::hard_q): one atomic per
+// wavefront, no divergent branch (idle lanes store into dump slots behind the queue)
+__device__ __forceinline__ void hard_push(const RtDevParams& P, lanemask m, V3 p, V3 n, V3 view, uint32_t mat_row, uint32_t light,
+                                          uint32_t pix, V3 Wa, uint32_t mult) {
+  const uint32_t cnt = (uint32_t)__popcll(m);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63u) == 0) base = atomicAdd(P.hard_count, cnt);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const uint32_t rankl = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  // (the host sizes the queue for every pair of the launch: base + rank < capacity)
+  const uint32_t i = (lane_of(m) && base + rankl < P.hard_capacity) ? base + rankl : P.hard_capacity + (threadIdx.x & 63u);
+  const size_t stride = (size_t)P.hard_capacity + 64u;
+  P.hard_q[0 * stride + i] = make_float4(p.x, p.y, p.z, __uint_as_float(mat_row));
+  P.hard_q[1 * stride + i] = make_float4(n.x, n.y, n.z, __uint_as_float(light));
+  P.hard_q[2 * stride + i] = make_float4(view.x, view.y, view.z, __uint_as_float(pix));
+  P.hard_q[3 * stride + i] = make_float4(Wa.x, Wa.y, Wa.z, __uint_as_float(mult));
+}
+
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
 #define RT_STASH_FIELDS 10u
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
-template <bool CULL, bool PRE>
+// STREAM: secondary rays exist (reflections / refractions): children are queued, pixel sums go through the fixed-point
+// accumulator, hard soft-shadow pairs are deferred.  The frames without them (configs 1-3) run a kernel that does not
+// contain any of that code.
+template <bool CULL, bool PRE, bool STREAM>
 __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevParams& P, Wave& wv, bool have,
                                               const RayIn& r, float* stash /* LDS: [RT_STASH_FIELDS][256] */,
                                               Hit pre) {
@@ -1173,7 +1208,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   WaveCtx& W = wv.ctx;
   const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
   const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
-  const bool stream = P.q_out != nullptr;
+  const bool stream = STREAM && P.q_out != nullptr;
 
   const unsigned long long t_all = PROF_T();
   V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
@@ -1328,6 +1363,23 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       if (!use_m) {
           continue;
       }
+    }
+    if (STREAM && cand.count == RT_CAND_OVERFLOW && P.hard_q && N > 1 && N <= 64u && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles &&
+        P.cand_cap != 0u) {
+      // The shared list overflowed: 64 unrelated hit points (an incoherent wavefront).  One wave-cooperative walk per
+      // sample over the union of what 64 unrelated rays reach costs ~1e5 instructions (0.3 % of config 4's sets were
+      // 26 % of its frame time).  The lanes' (hit point, light) pairs go to rt_hard_kernel instead, which spreads
+      // the N samples of a pair over N lanes; their contribution reaches the pixel through the accumulator.
+      uint32_t tix = threadIdx.x;
+      RT_OPAQUE(tix);
+      const float* st = stash + tix;
+      const float a0 = st[3 * 256];
+      int hd, hk;
+      uint32_t hmult;
+      unpack_dkm(__float_as_int(st[5 * 256]), hd, hk, hmult);
+      hard_push(P, use_m, sf.p, sf.n, d, __float_as_uint(st[6 * 256]), l, __float_as_uint(st[9 * 256]),
+                mk(st[0 * 256] * a0, st[1 * 256] * a0, st[2 * 256] * a0), hmult);
+      continue;
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
 #if RT_PROFILE == 3
@@ -1573,7 +1625,7 @@ __device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c
 // few adjacent pixels -- maximally coherent for the wave-cooperative traversal.  Sample colours meet in LDS and
 // are summed per pixel in the reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
 // ------------------------------------------------------------------------------------------------
-template <bool CULL>
+template <bool CULL, bool STREAM>
 __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
                                              float* lds_stash, unsigned long long* lds_cnt) {
   Wave wv;
@@ -1633,7 +1685,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   Hit none;
   none.t = INFINITY;
   none.id = -1;
-  RayOut out = process_ray<CULL, false>(sc, P, wv, pix_on, r, lds_stash, none);
+  RayOut out = process_ray<CULL, false, STREAM>(sc, P, wv, pix_on, r, lds_stash, none);
 
   // ---- per-pixel accumulation of the samples ----------------------------------------------------------
   V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
@@ -1691,7 +1743,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
     }
     if (any) {
       wrote = true;
-      if (P.acc) {
+      if (STREAM && P.acc) {
         // secondary rays are streaming: the pixel is resolved by rt_resolve_kernel
         acc_add(P, pix, color, 1u);
         P.acc[4 * (size_t)pix + 3] = 1;
@@ -1723,9 +1775,20 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScen
   __shared__ float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    primary_body<true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+    primary_body<true, false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   else
-    primary_body<false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+    primary_body<false, false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+}
+
+// the same with secondary rays (children queued, accumulator, hard pairs): launched when reflections / refractions are on
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ float4 lds_rgbh[256];
+  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ unsigned long long lds_cnt[16];
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    primary_body<true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+  else
+    primary_body<false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1845,7 +1908,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
     have = h.id >= 0;                // misses sort to the end: whole wavefronts fall through
     if (have) r = load_queued_ray(P, (size_t)P.q_in_first + j);
   }
-  RayOut out = process_ray<CULL, true>(sc, P, wv, have, r, lds_stash, h);
+  RayOut out = process_ray<CULL, true, true>(sc, P, wv, have, r, lds_stash, h);
   if (out.hit) acc_add(P, out.pix, out.contrib, out.mult);
   wave_flush(wv, P, 0ull, lds_cnt);
 }
@@ -1857,6 +1920,149 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_shade_kernel(RtDevScene 
     shade_body<true>(sc, P, lds_stash, lds_cnt);
   else
     shade_body<false>(sc, P, lds_stash, lds_cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rt_hard_kernel: the soft-shadow light of one (hit point, light) pair per N lanes -- lane j traces sample j
+// (PointLight::to_point_light_cloud, light.rs:183-225; has_any_intersection, raytracer.rs:24-106; calculate_lighting,
+// raytracer_renderer.rs:731-874) -- for the pairs the render kernels deferred (incoherent wavefronts).  The N shadow rays
+// of a pair leave one point towards a small cloud, and every lane walks the BVH for its OWN ray: stackless, over the
+// threaded copy of the tree (skip links), with per-lane vector loads; a lane alone visits ~50 nodes where the union of
+// 64 unrelated rays visits thousands.  The samples' contributions are summed over the N lanes in a fixed order and
+// added to the pixel accumulator (linear in the light's share of `direct` and `specular`, :206-209,:251-257).
+// ------------------------------------------------------------------------------------------------
+template <bool CULL>
+__device__ __forceinline__ void shadow_tris_lane(const RtDevScene& sc, lanemask grp, V3 o, V3 d, float tmax, Shadow& S) {
+  const BoxRay br = box_ray(o, d);
+  const float tl = t_limit_slack(tmax);
+  uint32_t n_exact = 0;
+  // entry `node` of the threaded tree: a missed box jumps to its skip link, a hit box steps to the next entry (its
+  // first child or -- after a leaf -- the same as its skip link)
+  uint32_t node = 0;
+  for (;;) {
+    const lanemask live = grp & ~S.occ & wave_ballot(node < sc.n_thr);
+    if (!live) break;
+    const bool on = lane_of(live);
+    const uint32_t at = sc.off_nodes_thr + (on ? node : 0u) * 32u;
+    const float4 b0 = vload<float4>(sc, at), b1 = vload<float4>(sc, at + 16u);
+    const float lo[3] = {b0.x, b0.y, b0.z}, hi[3] = {b1.x, b1.y, b1.z};
+    float tn, tm;
+    box_one(lo, hi, br, tn, tm);
+    const float slack = __builtin_fmaf(fabsf(tm), 4e-6f, tm + 1e-5f);
+    const lanemask hitbox = live & wave_ballot(tn <= fminf(slack, tl)) & wave_ballot(slack >= 0.0f);
+    const uint32_t leaf = __float_as_uint(b1.w);
+    lanemask todo = hitbox & wave_ballot((leaf >> 24) != 0u);
+    for (uint32_t k = 0; todo; k++) {  // the triangles of the lanes' leaves, one per lane per round
+      todo &= wave_ballot(k < (leaf >> 24)) & ~S.occ;
+      if (!todo) break;
+      const uint32_t slot = lane_of(todo) ? (leaf & 0xFFFFFFu) + k : 0u;
+      const float4 q0 = vload<float4>(sc, sc.off_tri_isect + slot * 48u);
+      const float4 q1 = vload<float4>(sc, sc.off_tri_isect + slot * 48u + 16u);
+      const float4 q2 = vload<float4>(sc, sc.off_tri_isect + slot * 48u + 32u);
+      float t;
+      lanemask h = tri_hit(q0, q1, q2, o, d, todo, tmax, t, n_exact);
+      h &= wave_ballot(t <= tmax);
+      if (h) {
+        const float4 sh = vload<float4>(sc, sc.off_tri_shade + slot * 16u);
+        const Mat m = load_mat(sc, lane_of(h) ? __float_as_uint(sh.w) : 0u);
+        shadow_accumulate_lane<CULL>(S, m, mk(sh.x, sh.y, sh.z), d, h);
+      }
+    }
+    node = on ? (lane_of(hitbox) ? node + 1u : __float_as_uint(b0.w)) : node;
+  }
+}
+
+template <bool CULL>
+__device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParams& P) {
+  const uint32_t N = P.light_mult;   // 2..64 (host)
+  const uint32_t ppw = 64u / N;      // pairs per wavefront
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t pw = lane / N, j = lane - pw * N;
+  const uint32_t pair = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ppw + pw;
+  const bool have = pw < ppw && pair < P.hard_in_count;
+  const lanemask grp = wave_ballot(have);
+  if (!grp) return;
+  const size_t stride = (size_t)P.hard_capacity + 64u;
+  const uint32_t at = have ? pair : 0u;
+  const float4 r0 = P.hard_q[0 * stride + at], r1 = P.hard_q[1 * stride + at], r2 = P.hard_q[2 * stride + at],
+               r3 = P.hard_q[3 * stride + at];
+  const V3 p = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z), view = mk(r2.x, r2.y, r2.z), Wa = mk(r3.x, r3.y, r3.z);
+  const uint32_t l = have ? __float_as_uint(r1.w) : 0u, pix = __float_as_uint(r2.w), mult = __float_as_uint(r3.w);
+  const Mat m = load_mat(sc, have ? __float_as_uint(r0.w) : 0u);
+  const float4 L0 = vload<float4>(sc, sc.off_lights + l * 32u), L1 = vload<float4>(sc, sc.off_lights + l * 32u + 16u);
+  const V3 lc = mk(L1.x, L1.y, L1.z);
+  // sample j of the pixel's cloud set of this light (light.rs:218; the table holds offset * (fw, fh, fd))
+  const uint32_t hsh = rt_cloud_hash(P.cloud_seed, pix, l);
+  const uint32_t set = (P.n_cloud_sets & (P.n_cloud_sets - 1u)) == 0u ? (hsh & (P.n_cloud_sets - 1u)) : (hsh % P.n_cloud_sets);
+  const float4 cs = have ? P.cloud_sets[(size_t)set * N + j] : make_float4(0, 0, 0, 0);
+  const float lI = (1.0f / (float)N) * L0.w;
+  // the shadow ray, exactly as the render kernels set it up (raytracer_renderer.rs:770-790)
+  const V3 lp = mk(L0.x + cs.x, L0.y + cs.y, L0.z + cs.z);
+  const V3 ltp = lp - p;
+  const float lmag = mag(ltp);
+  const V3 ld = ltp * (1.0f / lmag);
+  const V3 so = p + ld * mk(P.eps_distance, P.eps_distance, P.eps_distance);
+  const float tmax = mag(lp - so);
+  const V3 d = normalize_unit(ld, grp);
+  Shadow S;
+  S.occ = 0ull;
+  S.opacity = 1.0f;
+  S.filter = mk(1.0f, 1.0f, 1.0f);
+  for (uint32_t i = 0; i < sc.n_spheres; i++) {  // spheres: few, tested by the whole wavefront one by one
+    const float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
+    float t = 0.0f;
+    lanemask h = grp & ~S.occ & wave_ballot(sphere_hit(s, so, d, t));
+    h &= wave_ballot(t <= tmax);
+    if (h) {
+      const V3 sp = fma_s(d, t, so);
+      const V3 sn = normalize(sp - mk(s.x, s.y, s.z));
+      const Mat sm = load_mat_u(sc, sload<uint32_t>(sc, sc.off_sphere_mat + i * 4u));
+      if (CULL && !sm.transmissive) h &= wave_ballot(dot(d, sn) < 0.75f);
+      shadow_accumulate(S, sm, sn, d, h);
+    }
+  }
+  shadow_tris_lane<CULL>(sc, grp, so, d, tmax, S);
+  // PointLight::calculate_contribution_at + the light's share of calculate_lighting: the same colour-only arithmetic
+  // as the render kernels' add_light (FILTERED form)
+  V3 dl = mk(0, 0, 0), ds = mk(0, 0, 0);
+  {
+    const bool reach = have && !lane_of(S.occ);
+    const float dist = lmag + RT_EPS;
+    const float diff = dot(n, ld);
+    const float att = 0.95f * (RT_EPS + dist + dist * dist);
+    const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(att * -2.885390082f))
+                                    : clampf((tanhf(att) + 1.0f) / 2.0f, 0.0f, 1.0f);
+    const float cint = diff * lI * sig;
+    const V3 mc_lc = m.color * lc;
+    const V3 Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
+    const bool has_spec = m.shininess > 0.0f;
+    float specf = 0.0f;
+    if (has_spec) {
+      const V3 rr = fast_normalize(fma_s(n, -2.0f * diff, ld));
+      const float base = fmaxf(dot(rr, view), 0.0f);
+      specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(m.shininess * 512.0f, 1.0f)) : powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
+    }
+    const float light_factor = diff * cint * S.opacity, spec_factor = cint * S.opacity * specf;
+    if (reach && diff > 0.0f) {
+      dl = (m.color * Lc) * light_factor;
+      if (has_spec) ds = lc * spec_factor;
+    }
+  }
+  // sum over the pair's N lanes, fixed order (deterministic): lane j accumulates lanes j + 1, j + 2, j + 4, ...
+  V3 own = m.transmissive ? ds : (dl + ds);  // :251-257
+#pragma unroll
+  for (uint32_t off = 1; off < 64u; off <<= 1) {
+    const float ox = __shfl_down(own.x, off, 64), oy = __shfl_down(own.y, off, 64), oz = __shfl_down(own.z, off, 64);
+    if (j + off < N) own = mk(own.x + ox, own.y + oy, own.z + oz);
+  }
+  if (have && j == 0) acc_add(P, pix, Wa * own, mult);
+}
+
+__global__ __launch_bounds__(256) void rt_hard_kernel(RtDevScene sc, RtDevParams P) {
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    hard_body<true>(sc, P);
+  else
+    hard_body<false>(sc, P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1900,7 +2106,10 @@ uint32_t rt_primary_total_wgs(const RtDevParams& p) {
 
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;  // nothing owned inside the window
-  hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  if (p.acc)
+    hipLaunchKernelGGL(rt_primary_stream_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else
+    hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
@@ -1915,6 +2124,15 @@ int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream) {
   uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
   if (n_wgs == 0) return 0;
   hipLaunchKernelGGL(rt_shade_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+  const uint32_t ppw = 64u / (p.light_mult < 2u ? 2u : p.light_mult);
+  const uint32_t pairs_per_wg = 4u * (ppw ? ppw : 1u);
+  const uint32_t n_wgs = (p.hard_in_count + pairs_per_wg - 1u) / pairs_per_wg;
+  if (n_wgs == 0) return 0;
+  hipLaunchKernelGGL(rt_hard_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
