@@ -17,12 +17,11 @@ tag, wl = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "c3")
 kname = {"c1": "rt_primary_kernel", "c2": "rt_primary_kernel", "c3": "rt_primary_kernel"}.get(wl, "rt_shade_kernel")
 src = os.path.join("gpurun_out", f"prof_{tag}_{wl}")
 os.makedirs("profiles", exist_ok=True)
-build_id = open(os.path.join(src, "build_id.txt")).read().strip()
+build_id = open(os.path.join(src, "build_id.txt")).read().split()[0]
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", f"{tag}_{wl}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
-prim = [r for r in rows if "rt_primary_kernel" in r["Name"]]
-n_frames = int(prim[0]["Calls"]) if prim else 1  # one primary launch per frame (whole-frame chunks)
+n_frames = 4  # tools/profile.sh: --steps 3 --warmup 1
 kern = [r for r in rows if kname in r["Name"]][0]
 calls = int(kern["Calls"])
 per_frame = calls / n_frames
