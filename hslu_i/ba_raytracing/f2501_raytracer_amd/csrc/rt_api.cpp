@@ -257,6 +257,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       o[0] = r[RT_MAT_R], o[1] = r[RT_MAT_G], o[2] = r[RT_MAT_B], o[3] = r[RT_MAT_METALLIC];
       o[4] = r[RT_MAT_SHININESS], o[5] = r[RT_MAT_IOR], o[6] = r[RT_MAT_OPACITY], o[7] = r[RT_MAT_BOOST];
       o[8] = r[RT_MAT_HAS_OPACITY];
+      // constants of compute_fresnel against other_ior = 1.0 (every shadow ray, raytracer.rs:64-66): the two IEEE
+      // divisions of a wave-uniform material would otherwise run on the vector ALU per occluder hit per sample.
+      // volatile: no host-side contraction; the same single-precision operations the kernel would execute.
+      volatile float ior = r[RT_MAT_IOR], one = 1.0f;
+      volatile float inv_ior = one / ior;
+      volatile float q = (one - ior) / (one + ior);
+      volatile float f0 = q * q;
+      o[9] = inv_ior, o[10] = f0;
     }
     put(&s->dev.off_materials, m.data(), m.size() * 4);
     std::vector<float> l(8 * (size_t)d->n_lights, 0.f);

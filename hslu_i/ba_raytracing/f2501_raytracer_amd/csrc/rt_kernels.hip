@@ -191,6 +191,7 @@ __device__ __forceinline__ float fast_pow01(float b, float e) {
 struct Mat {
   V3 color;
   float metallic, shininess, ior, opacity, boost;
+  float inv_ior, f0_air;  // host: 1 / ior and ((1 - ior) / (1 + ior))^2, compute_fresnel's constants against other_ior = 1
   bool transmissive;  // TransmissionProperties::mask, material.rs:44-50
 };
 
@@ -205,6 +206,8 @@ __device__ __forceinline__ Mat load_mat(const RtDevScene& sc, uint32_t idx) {
   m.ior = b.y;
   m.opacity = b.z;
   m.boost = b.w;
+  m.inv_ior = c.y;
+  m.f0_air = c.z;
   m.transmissive = (c.x != 0.0f) && !(fabsf(m.opacity - 0.0f) <= RT_EPS);
   return m;
 }
@@ -221,6 +224,8 @@ __device__ __forceinline__ Mat load_mat_u(const RtDevScene& sc, uint32_t idx) {
   m.ior = b.y;
   m.opacity = b.z;
   m.boost = b.w;
+  m.inv_ior = c.y;
+  m.f0_air = c.z;
   m.transmissive = (c.x != 0.0f) && !(fabsf(m.opacity - 0.0f) <= RT_EPS);
   return m;
 }
@@ -247,6 +252,28 @@ __device__ __forceinline__ V3 fresnel_reflectance(const Mat& m, V3 normal, V3 vi
   V3 fres = mk(f0v.x + (1.0f - f0v.x) * c5, f0v.y + (1.0f - f0v.y) * c5, f0v.z + (1.0f - f0v.z) * c5);
   float ra = reflective ? m.metallic : 1.0f;
   return tir ? mk(ra, ra, ra) : fres;
+}
+
+// The same against other_ior = 1.0 -- what every shadow ray asks (raytracer.rs:64-66) -- with the two divisions of
+// the material's constants taken from the host (bit-identical: ior / 1.0f == ior, 1.0f / ior and q * q are the same
+// single-precision operations).  Red channel only: the shadow opacity uses transmittance.red.
+__device__ __forceinline__ float fresnel_reflectance_air_red(const Mat& m, V3 normal, V3 view) {
+  if (!m.transmissive) return m.metallic;
+  float n_dot_v = dot(normal, view);
+  float cos_theta = fabsf(n_dot_v);
+  bool inside = n_dot_v < 0.0f;
+  float eta_t = inside ? m.ior : m.inv_ior;
+  float sin2_t = eta_t * eta_t * (1.0f - cos_theta * cos_theta);
+  bool reflective = m.metallic > 0.0f;
+  bool tir = (inside && sin2_t > 1.0f) || reflective;
+  float omt = 1.0f - m.metallic;
+  float f0x = m.f0_air * omt + m.color.x * m.metallic;
+  float c1 = 1.0f - cos_theta;
+  float c2 = c1 * c1;
+  float c5 = c1 * (c2 * c2);
+  float fres = f0x + (1.0f - f0x) * c5;
+  float ra = reflective ? m.metallic : 1.0f;
+  return tir ? ra : fres;
 }
 
 // Material::absorption, material.rs:213-231
@@ -403,10 +430,7 @@ struct Shadow {
 // (predicated, outside divergent control flow, so that S.occ stays a wave-uniform mask; m is wave-uniform)
 __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
   float io = 0.0f;
-  if (m.transmissive) {
-    V3 refl = fresnel_reflectance(m, n, -d, 1.0f);
-    io = m.opacity * (1.0f - refl.x);
-  }
+  if (m.transmissive) io = m.opacity * (1.0f - fresnel_reflectance_air_red(m, n, -d));
   const bool on = lane_of(h);
   const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
   S.opacity = on ? nop : S.opacity;
@@ -419,8 +443,7 @@ __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n,
 template <bool CULL>
 __device__ __forceinline__ void shadow_accumulate_lane(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
   if (CULL) h &= wave_ballot(m.transmissive || dot(d, n) < 0.75f);  // sphere.rs:137-151, triangle.rs:154-168
-  const V3 refl = fresnel_reflectance(m, n, -d, 1.0f);
-  const float io = m.transmissive ? m.opacity * (1.0f - refl.x) : 0.0f;
+  const float io = m.transmissive ? m.opacity * (1.0f - fresnel_reflectance_air_red(m, n, -d)) : 0.0f;
   const bool on = lane_of(h);
   const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
   S.opacity = on ? nop : S.opacity;
@@ -915,8 +938,11 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
     h &= wave_ballot(t <= tmax);
     if (h) {
       // (computed for every lane, applied to the lanes in h: keeps S.occ a wave-uniform mask)
+      // The occluder's normal only feeds the Fresnel factor of a TRANSMISSIVE sphere, i.e. the light's colour (opacity
+      // reaches the occlusion decision only for opaque occluders, where io = 0 whatever the normal): 1-ulp rsq instead
+      // of IEEE sqrt + division.  With backface culling the normal decides a hit and stays exact.
       V3 p = fma_s(d, t, o);
-      V3 n = normalize(p - mk(s.x, s.y, s.z));
+      V3 n = CULL ? normalize(p - mk(s.x, s.y, s.z)) : fast_normalize(p - mk(s.x, s.y, s.z));
       Mat m = load_mat_u(sc, sload<uint32_t>(sc, sc.off_sphere_mat + i * 4u));
       if (CULL && !m.transmissive) h &= wave_ballot(dot(d, n) < 0.75f);
       shadow_accumulate(S, m, n, d, h);
@@ -2015,7 +2041,7 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
     h &= wave_ballot(t <= tmax);
     if (h) {
       const V3 sp = fma_s(d, t, so);
-      const V3 sn = normalize(sp - mk(s.x, s.y, s.z));
+      const V3 sn = CULL ? normalize(sp - mk(s.x, s.y, s.z)) : fast_normalize(sp - mk(s.x, s.y, s.z));
       const Mat sm = load_mat_u(sc, sload<uint32_t>(sc, sc.off_sphere_mat + i * 4u));
       if (CULL && !sm.transmissive) h &= wave_ballot(dot(d, sn) < 0.75f);
       shadow_accumulate(S, sm, sn, d, h);
