@@ -777,3 +777,20 @@ def test_default_features_match_reference_output_png_by_region():
         assert dm <= 0.75, (name, "mean", dm)
         assert ds <= 0.02, (name, "contrast", ds)
         assert mae <= 1.6, (name, "MAE", mae)
+
+
+def test_progressive_bands_match_the_oracle():
+    """`render_progressive` (the tile-by-tile fill of the shared buffer the window shows) against the CPU
+    oracle, not just against one `render` call: a small frame, bands of one tile row, a pre-filled buffer."""
+    cfg = RenderConfig.from_features(["reflections"], width_override=200, height_override=150)
+    flat = scenes.test_scene(cfg).flatten()
+    fill = 0x00334455
+    buf = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+    bands = []
+    n = RaytracerRenderer(cfg, device=0).render_progressive(buf, flat, on_tiles=lambda b, w: bands.append(w))
+    assert n == len(bands) == -(-cfg.height // cfg.render_stride) and bands[0] == (0, 0, cfg.width, cfg.render_stride)
+    argb_o, _, _ = oracle_lib.render(flat, cfg, aux=False)
+    want = np.where(argb_o != 0, argb_o, fill).astype(np.uint32)
+    ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
+    assert np.array_equal(buf.buffer == fill, want == fill)  # the same pixels keep the fill
+    assert np.abs(ch(buf.buffer) - ch(want)).max() <= 1
