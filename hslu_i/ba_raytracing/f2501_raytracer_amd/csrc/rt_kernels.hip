@@ -1,4 +1,4 @@
-// rt_kernels.hip -- the per-pixel render loop as one hand-written gfx950 (CDNA4) kernel.
+// rt_kernels.hip -- the per-pixel render loop as hand-written gfx950 (CDNA4) kernels.
 //
 // Path implemented (reference file:line, all fp32):
 //   primary rays            src/renderer/raytracer_renderer.rs:1190-1357, src/renderer/mod.rs:146-209
@@ -13,14 +13,17 @@
 //   pixel pack              src/output/window.rs:105-109
 //
 // Execution model (MI355X-first, nothing like the reference's rayon + 8-lane packets):
-//   * every ray is an independent work item.  rt_primary_kernel: one thread per (pixel, AA sample),
-//     a wavefront = the samples of a few adjacent pixels; rt_trace_kernel / rt_shade_kernel: one
-//     thread per queued reflection / refraction ray (nearest hit, radix sort by hit point, shading in
-//     hit-point order).  Children are appended to per-level ray queues in HBM (SoA float4 planes, one
-//     atomic per wavefront) that the host drains deepest level first in frame-sized chunks; pixel sums
-//     of secondary rays use 64-bit fixed-point atomics (order independent, bit-reproducible);
-//   * soft shadows walk the BVH once per (wavefront, light): the N jittered shadow rays of a hit point
-//     share a candidate triangle list (beam-level conservative culling), kept in the lanes of a VGPR;
+//   * every ray is an independent work item.  rt_primary[_stream]_kernel: one thread per (pixel, DISTINCT AA sample) --
+//     repeats of the reference's sample table are traced once and weighted by their multiplicity -- a wavefront = the
+//     samples of a few adjacent pixels; rt_trace_kernel / rt_shade_kernel: one thread per queued reflection /
+//     refraction ray (nearest hit, radix sort by hit point, shading in hit-point order).  Children are appended to
+//     per-level ray queues in HBM (SoA float4 planes, one atomic per wavefront) that the host drains deepest level
+//     first in frame-sized chunks; pixel sums of secondary rays use 64-bit fixed-point atomics (order independent,
+//     bit-reproducible);
+//   * soft shadows walk the BVH once per (wavefront, light): the N jittered shadow rays of a hit point share a
+//     candidate triangle list (beam-level conservative culling), kept in the lanes of a VGPR.  Wavefronts whose hit
+//     points are unrelated (the list overflows) defer their (hit point, light) pairs to rt_hard_kernel: N samples on
+//     N lanes, every lane walking a threaded (stackless) copy of the tree for its own ray;
 //   * BVH traversal is WAVE-COOPERATIVE: the 64 rays of a wavefront walk the tree together.  The
 //     current node index is wave-uniform, node / triangle / sphere / light records are fetched with
 //     scalar loads (constant address space -> s_load_dwordx4/x16), and the traversal stack is ONE
@@ -28,6 +31,7 @@
 //     misses a box are masked for that subtree;
 //   * a conservative, staged triangle pre-filter keeps the IEEE division of the literal test for
 //     the few triangles some lane can actually hit;
+//   * latency bound (dependent scalar-load -> vote -> branch chains): compiled for 6 waves per SIMD;
 //   * no MFMA: this is branchy fp32 intersection math, not a contraction.
 //
 // Numerics: compiled with -ffp-contract=off; fused multiply-adds appear exactly where the
