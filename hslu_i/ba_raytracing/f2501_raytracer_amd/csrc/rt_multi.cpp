@@ -272,10 +272,12 @@ struct MultiCtx {
 };
 
 std::mutex g_multi_mutex;
-std::map<std::vector<int>, std::unique_ptr<MultiCtx>> g_multi;
+std::map<std::vector<int>, std::unique_ptr<MultiCtx>> g_multi;  // key: devices, then the force-RCCL flag
 
-int get_ctx(const std::vector<int>& devices, MultiCtx** out) {
-  auto it = g_multi.find(devices);
+int get_ctx(const std::vector<int>& devices, bool force_rccl, MultiCtx** out) {
+  std::vector<int> key(devices);
+  key.push_back(force_rccl ? 1 : 0);
+  auto it = g_multi.find(key);
   if (it != g_multi.end()) {
     *out = it->second.get();
     return RT_OK;
@@ -290,7 +292,7 @@ int get_ctx(const std::vector<int>& devices, MultiCtx** out) {
   }
   if (n > 1 && !distinct && !same)
     return fail(RT_ERR_UNSUPPORTED, "per_gpu must name distinct GPUs (RCCL), or one GPU for all ranks (rehearsal)");
-  m->transport = n == 1 ? RT_TRANSPORT_NONE : (distinct ? RT_TRANSPORT_RCCL : RT_TRANSPORT_LOCAL);
+  m->transport = n == 1 ? RT_TRANSPORT_NONE : ((distinct || force_rccl) ? RT_TRANSPORT_RCCL : RT_TRANSPORT_LOCAL);
   if (m->transport == RT_TRANSPORT_RCCL) {
     m->nccl.assign(n, nullptr);
     NCCL_TRY(ncclCommInitAll(m->nccl.data(), (int)n, devices.data()));
@@ -309,7 +311,7 @@ int get_ctx(const std::vector<int>& devices, MultiCtx** out) {
   HIP_TRY(hipSetDevice(devices[0]));
   HIP_TRY(hipEventCreateWithFlags(&m->peer_done, hipEventDisableTiming));
   *out = m.get();
-  g_multi[devices] = std::move(m);
+  g_multi[key] = std::move(m);
   return RT_OK;
 }
 
@@ -337,7 +339,7 @@ int rt_render_multi(rt_scene* const* per_gpu, int n_gpu, const rt_params* params
   std::lock_guard<std::mutex> lock(g_multi_mutex);  // one multi-GPU frame at a time per process
   auto t_begin = std::chrono::steady_clock::now();
   MultiCtx* m = nullptr;
-  if ((rc = get_ctx(devices, &m)) != RT_OK) return rc;
+  if ((rc = get_ctx(devices, params->tuning.multi_force_rccl != 0, &m)) != RT_OK) return rc;
   const size_t n = (size_t)n_gpu;
   const size_t npix = (size_t)params->width * params->height;
 

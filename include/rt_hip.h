@@ -114,7 +114,10 @@ typedef struct rt_tuning {
   uint32_t chunk_log2;  /* log2 of the rays per secondary launch / primary batch; 0 = sized from free HBM */
   uint32_t no_aa_dedup; /* 1: trace every AA sample, also the bit-identical repeats of the sample table */
   uint32_t no_counters; /* 1: skip the ray counters of rt_stats (timing experiments) */
-  uint32_t reserved[4];
+  /* rt_render_multi, testing only: use the RCCL calls even when several ranks share one GPU (real RCCL refuses such a
+   * communicator; tests/mock_rccl checks the call sequence on a one-GPU box) */
+  uint32_t multi_force_rccl;
+  uint32_t reserved[3];
 } rt_tuning;
 
 typedef struct rt_params {

@@ -690,6 +690,60 @@ def test_render_multi_equals_render(features, kw):
     _lib.load().rt_multi_release()
 
 
+MOCK_RCCL_CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, _abi, _lib, scenes
+from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene, ImageBuffer, RaytracerRenderer
+lib = _lib.load()
+for features, kw in (([], {{}}), (["realistic", "anti_aliasing"], dict(depth_override=3))):
+    cfg = RenderConfig.from_features(features, **kw)
+    flat = scenes.test_scene(cfg).flatten()
+    fill = 0x00ABCDEF
+    ref = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+    RaytracerRenderer(cfg, device=0).render(ref, flat)
+    for n in (2, 3, 5):
+        ds = [DeviceScene(flat, 0) for _ in range(n)]
+        p, keep = _abi.make_params(cfg, tuning=dict(multi_force_rccl=1))
+        buf = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+        st = _abi.rt_stats()
+        arr = (C.c_void_p * n)(*[d.handle for d in ds])
+        _lib.check(lib.rt_render_multi(arr, n, C.byref(p), buf.buffer.ctypes.data, C.byref(st)))
+        bad = int((buf.buffer != ref.buffer).sum())
+        print("ranks", n, "features", features, "differing pixels", bad, flush=True)
+        assert bad == 0
+        for d in ds:
+            d.close()
+lib.rt_multi_release()
+print("MOCK-RCCL-OK", flush=True)
+"""
+
+
+def test_render_multi_rccl_call_sequence(tmp_path):
+    """The RCCL branch of rt_render_multi (ncclCommInitAll; one group of ncclRecv x (n-1) on the root + one ncclSend
+    per peer; scatter) on a one-GPU box: real RCCL refuses several ranks on one device, so a child process preloads
+    tests/mock_rccl (which checks that every receive has exactly one matching send of equal size and moves the bytes)
+    and asks for the RCCL transport with tuning.multi_force_rccl.  The gathered frame must equal the single-GPU one."""
+    import shutil
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc to build the mock")
+    so = tmp_path / "librccl_mock.so"
+    subprocess.check_call([hipcc, "-O1", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", "-o", str(so),
+                           os.path.join(here, "mock_rccl", "mock_rccl.cpp")])
+    env = dict(os.environ, LD_PRELOAD=str(so))
+    out = subprocess.run([sys.executable, "-c", MOCK_RCCL_CHILD.format(root=root, tests=here)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MOCK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ncclCommInitAll(5 ranks)" in out.stderr and "group of 8 operations matched" in out.stderr, out.stderr[-2000:]
+    assert "a receive has no matching send" not in out.stderr and "has no matching receive" not in out.stderr
+
+
 def test_render_gather_device_single_rank_and_errors():
     """The process-per-GPU entry points with one rank (no RCCL traffic): rt_comm_create / rt_render_gather_device /
     rt_comm_last_gather, HBM-resident frame."""
