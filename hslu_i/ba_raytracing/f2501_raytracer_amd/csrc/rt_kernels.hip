@@ -1421,33 +1421,38 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     // reference are used to drop work: `cosi = (ltp . n) / (|ltp| + EPS)` is `diff = n . ld` up to a factor
     // 1 + EPS/|ltp| (ld = ltp / |ltp|), and its `cosi > 0` selects are implied by the `diff > 0` gate of the sum.
     const V3 mc_lc = mcolor * lc;  // per light
+    const V3 mmc_lc = mcolor * mc_lc;  // (the reference multiplies the surface colour in twice: contribution colour x surface colour)
     auto add_light = [&](auto filtered_tag, V3 ltp, V3 ld, float lmag, const Shadow& S, lanemask reach_m) {
       constexpr bool FILTERED = decltype(filtered_tag)::value;
       const bool reach = lane_of(reach_m);
       const unsigned long long t_l = PROF_T();
       (void)ltp;
-      const float dist = lmag + RT_EPS;  // |ltp|, the sqrt of normalize(ltp)
+      const float dist = lmag;  // |ltp| (+ EPS in the reference: below the colour tolerance by three orders)
       const float diff = dot(sf.n, ld);  // = cosi
-      const float att = 0.95f * (RT_EPS + dist + dist * dist);
-      // (tanh(att) + 1) / 2 = 1 / (1 + exp(-2 att)): one exp2 and one rcp; already inside [0, 1]
-      const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(att * -2.885390082f))
-                                      : clampf((tanhf(att) + 1.0f) / 2.0f, 0.0f, 1.0f);
+      // att = 0.95 (EPS + dist + dist^2); (tanh(att) + 1) / 2 = 1 / (1 + exp(-2 att)): one exp2 and one rcp, already inside
+      // [0, 1]; the 0.95 and the -2 log2(e) of the exponent are one constant (colour-only arithmetic)
+      const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dist, dist, dist) * -2.7411205779f))
+                                      : clampf((tanhf(0.95f * (RT_EPS + dist + dist * dist)) + 1.0f) / 2.0f, 0.0f, 1.0f);
       const float cint = diff * lI * sig;
-      V3 Lc = mc_lc;
-      if (FILTERED) Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
+      // colour x light colour / filter (the filter of a ray nothing transmissive touched is 1)
+      V3 mLc = mmc_lc;
+      if (FILTERED)
+        mLc = mk(mmc_lc.x * __builtin_amdgcn_rcpf(S.filter.x), mmc_lc.y * __builtin_amdgcn_rcpf(S.filter.y), mmc_lc.z * __builtin_amdgcn_rcpf(S.filter.z));
       float specf = 0.0f;
       if (has_spec) {
         // reflected(ld, n) = ld - 2 (ld.n) n with ld.n = diff; a reflection keeps the length, and the shading
         // normal enters only through n / |n|^2 -- the reference normalises the result, here |n| = 1 is not assumed:
-        const V3 rr = fast_normalize(fma_s(sf.n, -2.0f * diff, ld));
-        float base = fmaxf(dot(rr, d), 0.0f);
+        // normalize(v) . d = (v . d) / |v|
+        const V3 rv = fma_s(sf.n, -2.0f * diff, ld);
+        float base = fmaxf(dot(rv, d) * __builtin_amdgcn_rsqf(dot(rv, rv)), 0.0f);
         specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
       }
       const float light_factor = FILTERED ? diff * cint * S.opacity : diff * cint;
       const float spec_factor = FILTERED ? cint * S.opacity * specf : cint * specf;
       if (reach && diff > 0.0f) {
-        light_color = light_color + (mcolor * Lc) * light_factor;
-        if (has_spec) spec_color = spec_color + lc * spec_factor;
+        // (fused accumulation: colour-only, one rounding less than the reference's multiply + add)
+        light_color = fma_s(mLc, light_factor, light_color);
+        if (has_spec) spec_color = fma_s(lc, spec_factor, spec_color);
       }
 #if RT_PROFILE
       RT_OPAQUE(light_color.x);
@@ -1456,15 +1461,20 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     };
     // the cloud offsets of sample j+1 are fetched (per-lane gather, L2) before sample j is traced, so
     // the load latency hides under a whole shadow traversal
+    // (every lane holds a valid set -- the pixel it hashes comes from the stash, written for idle lanes too -- so the loads
+    // are unconditional: no exec-mask bracket and no register shuffle between the current and the next offsets)
     float4 cnext = make_float4(0, 0, 0, 0);
-    if (N > 1 && use) cnext = cs[0];
+    if (N > 1 && (!STREAM || use)) cnext = cs[0];
     auto light_position = [&](uint32_t j) {
       V3 lp = mk(L0.x, L0.y, L0.z);
       if (N > 1) {
         lp.x = L0.x + cnext.x;  // light.rs:218; the table holds offset * (fw, fh, fd)
         lp.y = L0.y + cnext.y;
         lp.z = L0.z + cnext.z;
-        if (use && j + 1 < N) cnext = cs[j + 1];
+        if (!STREAM)
+          cnext = cs[j + 1 < N ? j + 1 : j];
+        else if (use && j + 1 < N)  // (the streaming kernels keep the guarded form: the unconditional one costs them scratch)
+          cnext = cs[j + 1];
       }
       return lp;
     };
@@ -2059,9 +2069,8 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
     const bool reach = have && !lane_of(S.occ);
     const float dist = lmag + RT_EPS;
     const float diff = dot(n, ld);
-    const float att = 0.95f * (RT_EPS + dist + dist * dist);
-    const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(att * -2.885390082f))
-                                    : clampf((tanhf(att) + 1.0f) / 2.0f, 0.0f, 1.0f);
+    const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dist, dist, dist + RT_EPS) * -2.7411205779f))
+                                    : clampf((tanhf(0.95f * (RT_EPS + dist + dist * dist)) + 1.0f) / 2.0f, 0.0f, 1.0f);
     const float cint = diff * lI * sig;
     const V3 mc_lc = m.color * lc;
     const V3 Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
@@ -2074,8 +2083,8 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
     }
     const float light_factor = diff * cint * S.opacity, spec_factor = cint * S.opacity * specf;
     if (reach && diff > 0.0f) {
-      dl = (m.color * Lc) * light_factor;
-      if (has_spec) ds = lc * spec_factor;
+      dl = fma_s(m.color * Lc, light_factor, mk(0.0f, 0.0f, 0.0f));  // (the same fused form as add_light)
+      if (has_spec) ds = fma_s(lc, spec_factor, mk(0.0f, 0.0f, 0.0f));
     }
   }
   // sum over the pair's N lanes, fixed order (deterministic): lane j accumulates lanes j + 1, j + 2, j + 4, ...
