@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 EXPORTS = (
     "rt_device_count", "rt_scene_create", "rt_render", "rt_render_device", "rt_render_collect_stats",
-    "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info", "rt_build_id",
+    "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info", "rt_build_id", "rt_selftest_exact_math",
     "rt_gather_layout", "rt_render_multi", "rt_multi_release", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy",
     "rt_render_gather_device", "rt_comm_last_gather",
 )
@@ -49,6 +49,8 @@ def load():
     lib.rt_scene_destroy.argtypes = [C.c_void_p]
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_build_id.restype = C.c_char_p
+    lib.rt_selftest_exact_math.restype = C.c_int
+    lib.rt_selftest_exact_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.rt_scene_bvh_info.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(rt_bvh_info)]
     u32p = C.POINTER(C.c_uint32)

@@ -38,6 +38,27 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 #endif
 const char* rt_build_id(void) { return RT_BUILD_ID; }
 
+int rt_selftest_exact_math(int device, const float* in, float* out_sqrt, float* out_rcp, uint32_t n) {
+  if (!in || !out_sqrt || !out_rcp) return fail(RT_ERR_INVALID_ARG, "null argument");
+  if (device < 0 || device >= rt_device_count()) return fail(RT_ERR_INVALID_ARG, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  DevBuf b;
+  int rc = b.ensure((size_t)n * 12 + 12);
+  if (rc != RT_OK) return rc;
+  float* d = (float*)b.p;
+  HIP_TRY(hipMemcpy(d, in, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipError_t e = (hipError_t)rt_launch_selftest_math(d, d + n, d + 2 * (size_t)n, n, nullptr);
+  if (e != hipSuccess) {
+    b.release();
+    return fail(RT_ERR_HIP, "selftest launch failed: %s", hipGetErrorString(e));
+  }
+  hipError_t e1 = hipMemcpy(out_sqrt, d + n, (size_t)n * 4, hipMemcpyDeviceToHost);
+  hipError_t e2 = hipMemcpy(out_rcp, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
+  b.release();
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(RT_ERR_HIP, "selftest copy failed");
+  return RT_OK;
+}
+
 int rt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

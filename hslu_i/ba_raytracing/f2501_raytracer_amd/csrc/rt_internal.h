@@ -169,6 +169,7 @@ int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* v
                   void* tmp, size_t* tmp_bytes, void* stream);
 int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
+int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);
 // multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame
 int rt_launch_scatter(uint32_t* argb, const uint32_t* recv, const uint32_t* rank_off, const uint32_t* tile_slot, uint32_t width,
                       uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t n_ranks, void* stream);

@@ -286,6 +286,10 @@ const char* rt_last_error(void);
  * only quoted for the build it was taken on) */
 const char* rt_build_id(void);
 
+/* diagnostics: the kernels' correctly rounded sqrt and reciprocal (normal-range sequences, csrc/rt_kernels.hip
+ * exact_sqrt / exact_rcp) evaluated on `n` host values on `device` -- tests compare them with IEEE sqrtf / division */
+int rt_selftest_exact_math(int device, const float* in, float* out_sqrt, float* out_rcp, uint32_t n);
+
 /* introspection for DESIGN.md / tests: BVH size of a created scene */
 typedef struct rt_bvh_info {
   uint32_t n_nodes;

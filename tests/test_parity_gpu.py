@@ -641,6 +641,37 @@ def test_repeated_aa_samples_are_traced_once_with_identical_results():
     assert np.abs(ch(outs[0][0]) - ch(argb_o)).max() <= 1
 
 
+def test_exact_sqrt_and_reciprocal_sequences_are_correctly_rounded():
+    """The kernels take sqrt and 1/x through their own normal-range correction sequences (exact_sqrt / exact_rcp in
+    csrc/rt_kernels.hip: hipcc's fsqrt / fdiv lowering without the denormal scaling).  Every hit / occlusion decision
+    and every t rests on them being bit-identical to IEEE: compared here with numpy's correctly rounded float32 sqrt and
+    division on 4 M operands -- random over the normal range, dense around 1 and around powers of two, exact squares
+    +- 1 ulp -- and on 0, inf and NaN."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    rng = np.random.default_rng(7)
+    parts = [
+        np.exp2(rng.uniform(-60, 60, 1 << 20)).astype(np.float32),             # the whole range a length can have
+        rng.uniform(0.0, 4.0, 1 << 20).astype(np.float32),                      # scene-sized lengths and discriminants
+        (1.0 + rng.integers(-4096, 4096, 1 << 19) * 2.0 ** -23).astype(np.float32),  # |ld|^2 of unit vectors
+        np.square(rng.uniform(1e-3, 1e3, 1 << 19).astype(np.float32)),         # exact squares ...
+    ]
+    sq = parts[3].view(np.uint32)
+    parts += [(sq + 1).view(np.float32), (sq - 1).view(np.float32)]            # ... and their neighbours
+    parts.append(np.exp2(np.arange(-100, 100)).astype(np.float32))
+    x = np.concatenate(parts + [np.array([0.0, np.inf, np.nan, 1.0, 2.0, 3.0, 0.5], np.float32)])
+    x = np.concatenate([x, -x[: 1 << 18]])                                     # negative operands of the reciprocal
+    got_s, got_r = np.empty_like(x), np.empty_like(x)
+    _lib.check(_lib.load().rt_selftest_exact_math(0, x.ctypes.data, got_s.ctypes.data, got_r.ctypes.data, x.size))
+    with np.errstate(all="ignore"):
+        want_s, want_r = np.sqrt(x), np.float32(1.0) / x
+    pos = x >= 0
+    bad_s = (got_s.view(np.uint32) != want_s.view(np.uint32)) & pos & ~np.isnan(want_s)
+    bad_r = (got_r.view(np.uint32) != want_r.view(np.uint32)) & ~np.isnan(want_r)
+    assert not bad_s.any(), f"{bad_s.sum()} sqrt results differ, e.g. x={x[bad_s][:4]} got={got_s[bad_s][:4]} want={want_s[bad_s][:4]}"
+    assert not bad_r.any(), f"{bad_r.sum()} reciprocals differ, e.g. x={x[bad_r][:4]} got={got_r[bad_r][:4]} want={want_r[bad_r][:4]}"
+    assert np.isnan(got_s[np.isnan(x)]).all() and np.isnan(got_r[np.isnan(x)]).all()
+
+
 # ---- the multi-GPU side of the boundary (rt_render_multi / rt_comm_*), rehearsed on the one GPU --------------------
 def render_multi(cfg, flat, n_ranks, window=None, fill=0, tile_size=None):
     """rt_render_multi with `n_ranks` scenes on device 0 (several ranks on one GPU: the tile partition, the compact
