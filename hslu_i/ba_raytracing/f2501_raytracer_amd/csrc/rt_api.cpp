@@ -70,7 +70,7 @@ void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
   for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb,
-                    &s->aux_id, &s->aux_t})
+                    &s->aux_id, &s->aux_t, &s->flag_geo, &s->flag_cell_tri, &s->flags})
     b->release();
   delete s;
 }
@@ -202,6 +202,51 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       put_shade(slot, t);
     }
     put(&s->dev.off_tri_isect, isect.data(), isect.size() * 4);
+    {
+      // Receiver cells: every triangle carries an R x R grid over its (u, v) coordinates, cells of about 1/128 of the
+      // scene's diagonal (R = 1 for the small triangles of a mesh, up to 128 for a wall).  The flags themselves depend on
+      // the light clouds and are computed by rt_flags_kernel when a frame first needs them (prepare()).
+      double diag2 = 0.0;
+      for (int a = 0; a < 3; a++) diag2 += (double)(s->aabb_hi[a] - s->aabb_lo[a]) * (s->aabb_hi[a] - s->aabb_lo[a]);
+      const double cell = std::sqrt(diag2) / 256.0;
+      std::vector<float> recv(12 * (size_t)nt), geo(12 * (size_t)nt);
+      std::vector<uint32_t> cell_tri;
+      for (uint32_t t = 0; t < nt; t++) {
+        const float *v1 = d->tri_v1 + 3 * (size_t)t, *e1 = d->tri_e1 + 3 * (size_t)t, *e2 = d->tri_e2 + 3 * (size_t)t;
+        const double n[3] = {(double)e1[1] * e2[2] - (double)e1[2] * e2[1], (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
+                             (double)e1[0] * e2[1] - (double)e1[1] * e2[0]};
+        const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        double l1 = 0, l2 = 0;
+        for (int a = 0; a < 3; a++) l1 += (double)e1[a] * e1[a], l2 += (double)e2[a] * e2[a];
+        uint32_t Rr = 0;
+        float* q = &recv[12 * (size_t)t];
+        if (nn > 0.0 && std::isfinite(nn) && cell > 0.0) {
+          Rr = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(std::sqrt(std::fmax(l1, l2)) / cell)));
+          // u = (p - v1) . (e2 x n) / n.n,  v = (p - v1) . (n x e1) / n.n
+          const double au[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+          const double av[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+          q[0] = (float)au[0], q[1] = (float)au[1], q[2] = (float)au[2], q[3] = (float)-(v1[0] * au[0] + v1[1] * au[1] + v1[2] * au[2]);
+          q[4] = (float)av[0], q[5] = (float)av[1], q[6] = (float)av[2], q[7] = (float)-(v1[0] * av[0] + v1[1] * av[1] + v1[2] * av[2]);
+          for (int k = 0; k < 8; k++)
+            if (!std::isfinite(q[k])) Rr = 0;
+        }
+        const uint32_t first = (uint32_t)cell_tri.size();
+        memcpy(&q[8], &Rr, 4), memcpy(&q[9], &first, 4);
+        q[10] = q[11] = 0.f;
+        float* g = &geo[12 * (size_t)t];
+        g[0] = v1[0], g[1] = v1[1], g[2] = v1[2], memcpy(&g[3], &Rr, 4);
+        g[4] = e1[0], g[5] = e1[1], g[6] = e1[2], memcpy(&g[7], &first, 4);
+        g[8] = e2[0], g[9] = e2[1], g[10] = e2[2], g[11] = 0.f;
+        cell_tri.insert(cell_tri.end(), (size_t)Rr * Rr, t);
+      }
+      put(&s->dev.off_recv, recv.data(), recv.size() * 4);
+      s->n_cells = (uint32_t)cell_tri.size();
+      if (s->n_cells) {
+        if ((rc = upload(s->flag_geo, geo.data(), geo.size() * 4)) != RT_OK) return bail(rc);
+        if ((rc = upload(s->flag_cell_tri, cell_tri.data(), cell_tri.size() * 4)) != RT_OK) return bail(rc);
+        if ((rc = s->flags.ensure((size_t)s->n_cells * 2 + 64)) != RT_OK) return bail(rc);
+      }
+    }
     put(&s->dev.off_tri_shade, shade.data(), shade.size() * 4);
     std::vector<uint32_t> ids(bvh.tri_order);
     for (uint32_t slot = 0; slot < n_slots; slot++)
@@ -467,6 +512,24 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     }
     const uint32_t cap = p->tuning.shadow_candidate_cap;
     P->cand_cap = cap == RT_CAND_CAP_NONE ? 0u : (cap ? cap : 64u);
+    // receiver flags: cells no triangle / sphere can shadow for a light skip the candidate walk (rt_flags_kernel)
+    P->recv_flags = nullptr;
+    if (!p->tuning.no_receiver_flags && P->cand_cap == 64u && s->n_cells && s->dev.n_lights <= 8u && p->traversal == RT_TRAVERSAL_BVH &&
+        !(p->flags & RT_FLAG_BACKFACE_CULLING) && P->cloud_delta > 0.0f) {
+      const float key[8] = {P->beam_delta, p->eps_distance, P->cloud_centre[0], P->cloud_centre[1], P->cloud_centre[2], 1.f, 0.f, 0.f};
+      if (memcmp(key, s->flags_key, sizeof(key)) != 0) {
+        if ((rc = begin_upload()) != RT_OK) return rc;  // (waits for kernels of an earlier frame that read the old flags)
+        RtDevParams B = *P;
+        B.flag_out = (uint16_t*)s->flags.p;
+        B.flag_geo = (const float4*)s->flag_geo.p;
+        B.flag_cell_tri = (const uint32_t*)s->flag_cell_tri.p;
+        B.n_cells = s->n_cells;
+        hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));
+        memcpy(s->flags_key, key, sizeof(key));
+      }
+      P->recv_flags = (const uint16_t*)s->flags.p;
+    }
   }
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;

@@ -80,6 +80,9 @@ struct RtDevScene {
   // planes and hi* the exit planes for that octant, children are in near-first order (octant o: [o * n_nodes ...])
   uint32_t off_nodes_oct;
   uint32_t off_nodes_thr;   // RtThrNode[n_thr]: the tree threaded for stackless per-lane walks
+  // receiver records, canonical triangle order, 48 B: {Au, au0} {Av, av0} {bits(R), bits(first cell), 0, 0} -- barycentric
+  // coordinates of a hit point p are u = Au.p + au0, v = Av.p + av0; the triangle's R x R cells start at `first cell`
+  uint32_t off_recv;
   uint32_t n_thr;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
   uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
@@ -108,6 +111,13 @@ struct RtDevParams {
   float cloud_centre[3];
   float cloud_delta;
   uint32_t cand_cap;  // give up candidate sharing for a (wavefront, light) above this many slots (<= 64)
+  // Receiver flags, one uint16 per receiver cell: bit l = no triangle can touch a soft-shadow ray from this cell towards
+  // light l, bit 8 + l = no sphere can (rt_flags_kernel; nullptr = not in use).  flag_*: inputs of that kernel.
+  const uint16_t* recv_flags;
+  uint16_t* flag_out;
+  const float4* flag_geo;         // canonical triangles: {v1, bits(R)} {e1, bits(first cell)} {e2, 0}
+  const uint32_t* flag_cell_tri;  // cell -> canonical triangle
+  uint32_t n_cells;
   uint32_t max_depth_reflection, max_depth_refraction;
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tile_size, n_ranks, rank;
@@ -169,6 +179,7 @@ int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* v
                   void* tmp, size_t* tmp_bytes, void* stream);
 int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
+int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);
 // multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame
 int rt_launch_scatter(uint32_t* argb, const uint32_t* recv, const uint32_t* rank_off, const uint32_t* tile_slot, uint32_t width,

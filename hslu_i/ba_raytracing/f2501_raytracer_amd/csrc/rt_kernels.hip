@@ -690,11 +690,29 @@ struct CandList {
   unsigned long long umbra;  // uniform lane mask: every sample ray of the lane certainly hits one opaque triangle
 };
 
-template <bool CULL>
+// Receiver flags (rt_flags_kernel, RtDevParams::recv_flags): the collection also runs ONCE PER SCENE over the cells of
+// every triangle as a receiver -- one lane = one cell (a parallelogram of the triangle's (u, v) grid), its beam the
+// tube from the cell's centre to the light cloud fattened by the cell's half diagonal r (origins within eps_o + r,
+// directions within delta + r), the t-rejection ("the surface the point lies on, and everything behind it") taken at the
+// cell's four EXACT corners (its left side is convex in the point, so the corners bound the cell).  A cell no triangle
+// survives for is flagged clear for that light: at render time a (wavefront, light) whose lanes all sit in clear cells
+// has no candidate triangle and skips the walk.
+struct FatBeam {
+  float r;       // every point of the cell lies within r (1-norm) of the beam origin
+  V3 pt[4];      // the cell's corners
+};
+enum { COLLECT_OWN = 0, COLLECT_FLAGS = 1 };
+
+// MODE: COLLECT_OWN -- a wavefront's own collection at render time; COLLECT_FLAGS -- fat beams of receiver cells (fb): no
+// list and no umbra, the result is L.umbra = lanes some triangle survives for, L.spheres = lanes (low / high word of the
+// mask in count / spheres) some sphere is near.
+template <bool CULL, int MODE = COLLECT_OWN>
 __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
-                                                              const RtDevParams& P, V3 p_first, float p_spread, uint32_t cand_cap) {
+                                                              const RtDevParams& P, V3 p_first, float p_spread, uint32_t cand_cap,
+                                                              const FatBeam* fb = nullptr, bool walk_tris = true) {
   RT_OPAQUE_S(cand_cap);
-  const float delta = P.beam_delta;
+  const float delta = MODE == COLLECT_FLAGS ? P.beam_delta + fb->r : P.beam_delta;
+  const float delta_e5 = MODE == COLLECT_FLAGS ? P.beam_delta_e5 + fb->r : P.beam_delta_e5;
   CandList L;
   L.reg = 0;
   L.count = 0;
@@ -708,8 +726,8 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
               clampf(__builtin_amdgcn_rcpf(dseg.z), -1e30f, 1e30f));
   V3 noi = mk(-(p.x * inv.x), -(p.y * inv.y), -(p.z * inv.z));
   V3 dl = mk(delta * fabsf(inv.x), delta * fabsf(inv.y), delta * fabsf(inv.z));  // box inflation in s units
-  float send = 1.0f + P.beam_delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f;  // past the cloud centre
-  float sbeg = -(P.beam_delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f);
+  float send = 1.0f + delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f;  // past the cloud centre
+  float sbeg = -(delta_e5 * __builtin_amdgcn_rcpf(len) + 1e-5f);
   // entry / exit parameters with the inflation folded into the fma constants: cn = noi - dl, cf = noi + dl
   const V3 cn = noi - dl, cf = noi + dl;
   auto box = [&](const float* lo, const float* hi, float& smin) {
@@ -752,9 +770,12 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   const float lenp = len + delta;
   const float rcp_lenp = __builtin_amdgcn_rcpf(lenp);
   const float t_push = P.beam_eps_push * rcp_lenp;
-  const float p_ulp = __builtin_fmaf(1.3e-7f, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)), P.beam_eps_ulp);  // 1.3e-7 (|p| + eps) + 2.5e-6 eps
+  // (receiver cell: the largest coordinate of any point of it; a hit point the cell stands for lies off the triangle's
+  // plane by the rounding of p = o + t d, hence the doubled ulp term; origins lie within eps_o + r of the cell's centre)
+  const float p_max = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) + (MODE == COLLECT_FLAGS ? fb->r : 0.0f);
+  const float p_ulp = __builtin_fmaf(MODE == COLLECT_FLAGS ? 4e-7f : 1.3e-7f, p_max, P.beam_eps_ulp);  // 1.3e-7 (|p| + eps) + 2.5e-6 eps
   // (p_ulp also carries G*eps_d for sum|x b_j| vs sum|x b0| and the rounding of the unit direction)
-  const float eps_o = __builtin_fmaf(2.6e-7f, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)), P.beam_eps_o);  // 1.01 eps + 2 p_ulp >= |so_j - p|
+  const float eps_o = __builtin_fmaf(2.6e-7f, p_max, P.beam_eps_o) + (MODE == COLLECT_FLAGS ? fb->r + 4e-7f * p_max : 0.0f);  // 1.01 eps + 2 p_ulp >= |so_j - p|
   // returns true when NO lane in `lanes` can be hit by any of its samples (wave-uniform result); staged so
   // that a triangle every lane rejects by its first barycentric alone costs a third of the arithmetic
   auto beam_rejects_all = [&](uint32_t slot, lanemask lanes) -> bool {
@@ -774,7 +795,22 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     // t: the surface the hit point lies on, and everything behind it
     float xbs = __uint_as_float(__float_as_uint(dot(x, b)) ^ sgn);
     float st0 = __builtin_fmaf(fabsf(x.x), fabsf(b.x), __builtin_fmaf(fabsf(x.y), fabsf(b.y), fabsf(x.z) * fabsf(b.z)));
-    lanemask rej = wave_ballot(__builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack));
+    lanemask rej;
+    if (MODE == COLLECT_FLAGS) {
+      // every corner of the cell on its own (the cell's centre alone proves nothing about its rim); ad - dslack and lenp
+      // bound |D_j.X| from below and |D_j| from above over the whole fat beam, so the inequality holds per point
+      const float rhs = t_push * (ad - dslack);
+      rej = ~0ull;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const V3 bk = mk(q0.x, q0.y, q0.z) - fb->pt[k];
+        const float xk = __uint_as_float(__float_as_uint(dot(x, bk)) ^ sgn);
+        const float sk = __builtin_fmaf(fabsf(x.x), fabsf(bk.x), __builtin_fmaf(fabsf(x.y), fabsf(bk.y), fabsf(x.z) * fabsf(bk.z)));
+        rej &= wave_ballot(__builtin_fmaf(4e-6f, sk, __builtin_fmaf(X1, p_ulp, xk)) < rhs);
+      }
+    } else {
+      rej = wave_ballot(__builtin_fmaf(4e-6f, st0, __builtin_fmaf(X1, p_ulp, xbs)) < t_push * (ad - dslack));
+    }
     if (!(lanes & (open | ~rej))) return true;
     // u
     V3 y = mk((c2.y * dseg.z) + (-c2.z * dseg.y), (c2.z * dseg.x) + (-c2.x * dseg.z), (c2.x * dseg.y) + (-c2.y * dseg.x));
@@ -790,6 +826,10 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     float sv = E1 * geo;
     rej |= wave_ballot(zbs + sv < 0.0f) | wave_ballot((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
     if (!(lanes & (open | ~rej))) return true;
+    if (MODE == COLLECT_FLAGS) {
+      L.umbra |= lanes & (open | ~rej);  // cells this triangle survives for
+      return true;                        // (nothing is listed)
+    }
     // Umbra: the triangle is opaque and EVERY sample ray of the lane hits it between origin and light -- the
     // literal test would accept it for each j (u_j, v_j >= 0, u_j + v_j < 1, EPS < t_j <= tmax_j, |det_j| > EPS,
     // all by margins that cover the rounding of the literal sequence), so the lane is occluded for this light
@@ -812,9 +852,22 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   };
   const unsigned long long grp = wave_ballot(alive);
   if (!grp) return L;
+  lanemask flags_near = 0ull;  // COLLECT_FLAGS: cells some sphere is near
   // spheres: every point of every sample ray lies within delta of the centre segment, so a sphere
   // whose centre is farther than r + delta from that segment cannot be touched by any of them
-  {
+  if (MODE == COLLECT_FLAGS) {
+    lanemask near_m = 0ull;
+    const float inv_len2 = __builtin_amdgcn_rcpf(fmaxf(dot(dseg, dseg), 1e-30f));
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+      const float4 sp4 = sload<float4>(sc, sc.off_spheres + i * 16u);
+      const V3 w = mk(sp4.x, sp4.y, sp4.z) - p;
+      const float sp = clampf(dot(w, dseg) * inv_len2, 0.0f, 1.0f);
+      const V3 q = w - dseg * sp;
+      const float reach = sload<float>(sc, sc.off_sphere_rad + i * 4u) + delta;
+      near_m |= wave_ballot(alive && dot(q, q) <= reach * reach * 1.0002f + 1e-12f);
+    }
+    flags_near = near_m;
+  } else {
     uint32_t mask = 0;
     const float inv_len2 = __builtin_amdgcn_rcpf(fmaxf(dot(dseg, dseg), 1e-30f));
     const uint32_t ns = sc.n_spheres < 32u ? sc.n_spheres : 32u;
@@ -856,6 +909,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     }
     L.spheres = mask | (sc.n_spheres > 32u ? 0xFFFFFFFFu : 0u);
   }
+  if (!walk_tris) return L;  // (wave-uniform: every lane sits in a receiver cell no triangle can shadow for this light)
   // direction octant of the wavefront (sign of inv = sign of dseg, -0 included)
   const unsigned long long mx = wave_ballot(__float_as_uint(inv.x) >> 31) & grp, my = wave_ballot(__float_as_uint(inv.y) >> 31) & grp,
                            mz = wave_ballot(__float_as_uint(inv.z) >> 31) & grp;
@@ -938,6 +992,10 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     walk(std::true_type{});
   else
     walk(std::false_type{});
+  if (MODE == COLLECT_FLAGS) {
+    L.count = (uint32_t)flags_near;
+    L.spheres = (uint32_t)(flags_near >> 32);
+  }
   return L;
 }
 
@@ -1239,7 +1297,7 @@ __device__ __forceinline__ void hard_push(const RtDevParams& P, lanemask m, V3 p
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-#define RT_STASH_FIELDS 10u
+#define RT_STASH_FIELDS 11u
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
 // STREAM: secondary rays exist (reflections / refractions): children are queued, pixel sums go through the fixed-point
 // accumulator, hard soft-shadow pairs are deferred.  The frames without them (configs 1-3) run a kernel that does not
@@ -1313,6 +1371,23 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   sf.mat = 0;
   if (hit) sf = surface_of(sc, h, r.o, d);
   stash[threadIdx.x + 6 * 256] = __uint_as_float(sf.mat);  // the material row is simply read again after the loop (L2)
+  if (N > 1) {
+    // receiver flags of the cell the hit point lies in (bit l: no triangle can shadow it for light l, bit 8 + l: no sphere)
+    uint32_t rflags = 0u;
+    if (P.recv_flags && hit && h.id >= (int)sc.n_spheres) {
+      const uint32_t ro = sc.off_recv + (uint32_t)(h.id - (int)sc.n_spheres) * 48u;
+      const float4 ru = vload<float4>(sc, ro), rv = vload<float4>(sc, ro + 16u);
+      const uint2 rr = vload<uint2>(sc, ro + 32u);  // {R, first cell}
+      const float Rf = (float)rr.x;
+      const float cu = (__builtin_fmaf(ru.x, sf.p.x, __builtin_fmaf(ru.y, sf.p.y, ru.z * sf.p.z)) + ru.w) * Rf;
+      const float cv = (__builtin_fmaf(rv.x, sf.p.x, __builtin_fmaf(rv.y, sf.p.y, rv.z * sf.p.z)) + rv.w) * Rf;
+      const uint32_t ci = (uint32_t)fminf(fmaxf(cu, 0.0f), Rf - 1.0f), cj = (uint32_t)fminf(fmaxf(cv, 0.0f), Rf - 1.0f);
+      // (cells beyond the hypotenuse carry no flags; the cells are computed 5 % larger than they are, which covers the
+      // rounding of u and v)
+      if (rr.x != 0u && ci + cj < rr.x) rflags = P.recv_flags[rr.y + ci + rr.x * cj];
+    }
+    stash[threadIdx.x + 10 * 256] = __uint_as_float(rflags);
+  }
   const Mat m_lit = load_mat(sc, sf.mat);
   const V3 mcolor = m_lit.color;
   const float mshin = m_lit.shininess;
@@ -1381,7 +1456,20 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     } else if (N > 1 && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles) {
       V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
       const unsigned long long t_c = PROF_T();
-      cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P, p_first, p_spread, P.cand_cap);
+      bool walk_tris = true, test_spheres = true;
+      if (!CULL && P.recv_flags) {
+        uint32_t tix = threadIdx.x;
+        RT_OPAQUE(tix);
+        const uint32_t rf = __float_as_uint(stash[10u * 256u + tix]) >> l;
+        walk_tris = (use_m & ~wave_ballot(rf & 1u)) != 0ull;
+        test_spheres = walk_tris || (use_m & ~wave_ballot((rf >> 8) & 1u)) != 0ull;
+      }
+      if (test_spheres) {
+        cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P, p_first, p_spread, P.cand_cap, nullptr, walk_tris);
+      } else {
+        cand.count = 0;  // every lane's cell is clear of triangles and spheres for this light: nothing to test
+        cand.spheres = 0;
+      }
 #if RT_PROFILE
       RT_OPAQUE(cand.reg);
 #endif
@@ -2149,6 +2237,52 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
   (void)wrote;
 }
 
+// ------------------------------------------------------------------------------------------------
+// rt_flags_kernel: one thread per receiver cell (see FatBeam / COLLECT_FLAGS).  Runs when a scene is first rendered with
+// soft shadows, and again when the light clouds' size changes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rt_flags_kernel(RtDevScene sc, RtDevParams P) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  const bool have = c < P.n_cells;
+  const uint32_t t = have ? P.flag_cell_tri[c] : 0u;
+  const float4 g0 = P.flag_geo[3u * t], g1 = P.flag_geo[3u * t + 1u], g2 = P.flag_geo[3u * t + 2u];
+  const uint32_t R = __float_as_uint(g0.w), first = __float_as_uint(g1.w);
+  const uint32_t local = have ? c - first : 0u;
+  const uint32_t j = R ? local / R : 0u, i = local - j * R;
+  const bool active = have && R != 0u && i + j < R;  // (cells beyond the hypotenuse are never looked up)
+  const V3 v1 = mk(g0.x, g0.y, g0.z), e1 = mk(g1.x, g1.y, g1.z), e2 = mk(g2.x, g2.y, g2.z);
+  const float inv_r = R ? 1.0f / (float)R : 0.0f;
+  // the cell, 5 % larger than it is on every side (a hit point's computed (u, v) may round across a cell border)
+  const float u0 = ((float)i - 0.05f) * inv_r, u1 = ((float)i + 1.05f) * inv_r, w0 = ((float)j - 0.05f) * inv_r, w1 = ((float)j + 1.05f) * inv_r;
+  FatBeam fb;
+  fb.pt[0] = v1 + e1 * u0 + e2 * w0;
+  fb.pt[1] = v1 + e1 * u1 + e2 * w0;
+  fb.pt[2] = v1 + e1 * u0 + e2 * w1;
+  fb.pt[3] = v1 + e1 * u1 + e2 * w1;
+  const V3 pm = v1 + e1 * (((float)i + 0.5f) * inv_r) + e2 * (((float)j + 0.5f) * inv_r);
+  float r = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const V3 dk = fb.pt[k] - pm;
+    r = fmaxf(r, fabsf(dk.x) + fabsf(dk.y) + fabsf(dk.z));
+  }
+  fb.r = __builtin_fmaf(r, 1.0001f, 4e-7f * (fabsf(pm.x) + fabsf(pm.y) + fabsf(pm.z)));
+  WaveCtx W;
+  W.n_nodes = W.n_tris = W.s_nodes = W.s_tris = W.s_passes = W.n_exact = W.s_exact = 0;
+  uint32_t flags = 0u;
+  for (uint32_t l = 0; l < sc.n_lights && l < 8u; l++) {
+    const float4 L0 = sload<float4>(sc, sc.off_lights + l * 32u);
+    const V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
+    const CandList cl = collect_light_candidates<false, COLLECT_FLAGS>(sc, W, active, pm, centre, P, pm, 0.0f, RT_MAX_CANDIDATES, &fb);
+    const lanemask near_m = (lanemask)cl.count | ((lanemask)cl.spheres << 32);
+    if (wave_ballot(active)) {
+      flags |= lane_of(cl.umbra) ? 0u : (1u << l);
+      flags |= lane_of(near_m) ? 0u : (1u << (8u + l));
+    }
+  }
+  if (have) P.flag_out[c] = (uint16_t)(active ? flags : 0u);
+}
+
 // diagnostics (rt_selftest_exact_math): the exact sequences on arbitrary operands
 __global__ __launch_bounds__(256) void rt_selftest_math_kernel(const float* in, float* out_sqrt, float* out_rcp, uint32_t n) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -2158,6 +2292,12 @@ __global__ __launch_bounds__(256) void rt_selftest_math_kernel(const float* in, 
 }
 
 }  // namespace
+
+int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream) {
+  if (p.n_cells == 0) return 0;
+  hipLaunchKernelGGL(rt_flags_kernel, dim3((p.n_cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
 
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream) {
   if (n == 0) return 0;

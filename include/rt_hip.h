@@ -117,7 +117,11 @@ typedef struct rt_tuning {
   /* rt_render_multi, testing only: use the RCCL calls even when several ranks share one GPU (real RCCL refuses such a
    * communicator; tests/mock_rccl checks the call sequence on a one-GPU box) */
   uint32_t multi_force_rccl;
-  uint32_t reserved[3];
+  /* 1: no receiver flags.  Default 0: with soft shadows every triangle carries a grid of receiver cells, flagged per light
+   * when no triangle / sphere can touch a shadow ray that starts in the cell (computed once per scene and light-cloud
+   * size by rt_flags_kernel); wavefronts whose hit points all lie in clear cells skip the candidate walk -- same image */
+  uint32_t no_receiver_flags;
+  uint32_t reserved[2];
 } rt_tuning;
 
 typedef struct rt_params {
