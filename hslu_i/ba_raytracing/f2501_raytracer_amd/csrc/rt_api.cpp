@@ -203,41 +203,62 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     put(&s->dev.off_tri_isect, isect.data(), isect.size() * 4);
     {
-      // Receiver cells: every triangle carries an R x R grid over its (u, v) coordinates, cells of about 1/128 of the
-      // scene's diagonal (R = 1 for the small triangles of a mesh, up to 128 for a wall).  The flags themselves depend on
+      // Receiver cells: every triangle carries an R x R grid over its (u, v) coordinates, cells of about 1/256 of the
+      // scene's diagonal (R = 1 for the small triangles of a mesh, up to 256 for a wall).  The flags themselves depend on
       // the light clouds and are computed by rt_flags_kernel when a frame first needs them (prepare()).
-      double diag2 = 0.0;
-      for (int a = 0; a < 3; a++) diag2 += (double)(s->aabb_hi[a] - s->aabb_lo[a]) * (s->aabb_hi[a] - s->aabb_lo[a]);
-      const double cell = std::sqrt(diag2) / 256.0;
+      double diag2 = 0.0, pmax = 0.0;
+      for (int a = 0; a < 3; a++) {
+        diag2 += (double)(s->aabb_hi[a] - s->aabb_lo[a]) * (s->aabb_hi[a] - s->aabb_lo[a]);
+        pmax = std::fmax(pmax, std::fmax(std::fabs((double)s->aabb_lo[a]), std::fabs((double)s->aabb_hi[a])));
+      }
       std::vector<float> recv(12 * (size_t)nt), geo(12 * (size_t)nt);
       std::vector<uint32_t> cell_tri;
-      for (uint32_t t = 0; t < nt; t++) {
-        const float *v1 = d->tri_v1 + 3 * (size_t)t, *e1 = d->tri_e1 + 3 * (size_t)t, *e2 = d->tri_e2 + 3 * (size_t)t;
-        const double n[3] = {(double)e1[1] * e2[2] - (double)e1[2] * e2[1], (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
-                             (double)e1[0] * e2[1] - (double)e1[1] * e2[0]};
-        const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-        double l1 = 0, l2 = 0;
-        for (int a = 0; a < 3; a++) l1 += (double)e1[a] * e1[a], l2 += (double)e2[a] * e2[a];
-        uint32_t Rr = 0;
-        float* q = &recv[12 * (size_t)t];
-        if (nn > 0.0 && std::isfinite(nn) && cell > 0.0) {
-          Rr = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(std::sqrt(std::fmax(l1, l2)) / cell)));
-          // u = (p - v1) . (e2 x n) / n.n,  v = (p - v1) . (n x e1) / n.n
-          const double au[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
-          const double av[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
-          q[0] = (float)au[0], q[1] = (float)au[1], q[2] = (float)au[2], q[3] = (float)-(v1[0] * au[0] + v1[1] * au[1] + v1[2] * au[2]);
-          q[4] = (float)av[0], q[5] = (float)av[1], q[6] = (float)av[2], q[7] = (float)-(v1[0] * av[0] + v1[1] * av[1] + v1[2] * av[2]);
-          for (int k = 0; k < 8; k++)
-            if (!std::isfinite(q[k])) Rr = 0;
+      // (a scene of many wall-sized triangles: coarser cells until the tables stay below 2^26 cells)
+      for (double cell = std::sqrt(diag2) / 256.0;; cell *= 2.0) {
+        cell_tri.clear();
+        uint64_t total = 0;
+        for (uint32_t t = 0; t < nt; t++) {
+          const float *v1 = d->tri_v1 + 3 * (size_t)t, *e1 = d->tri_e1 + 3 * (size_t)t, *e2 = d->tri_e2 + 3 * (size_t)t;
+          const double n[3] = {(double)e1[1] * e2[2] - (double)e1[2] * e2[1], (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
+                               (double)e1[0] * e2[1] - (double)e1[1] * e2[0]};
+          const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+          double l1 = 0, l2 = 0;
+          for (int a = 0; a < 3; a++) l1 += (double)e1[a] * e1[a], l2 += (double)e2[a] * e2[a];
+          uint32_t Rr = 0;
+          float* q = &recv[12 * (size_t)t];
+          for (int k = 0; k < 12; k++) q[k] = 0.f;
+          if (nn > 0.0 && std::isfinite(nn) && cell > 0.0) {
+            Rr = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(std::sqrt(std::fmax(l1, l2)) / cell)));
+            // u = (p - v1) . (e2 x n) / n.n,  v = (p - v1) . (n x e1) / n.n
+            const double au[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+            const double av[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+            const double au0 = -(v1[0] * au[0] + v1[1] * au[1] + v1[2] * au[2]), av0 = -(v1[0] * av[0] + v1[1] * av[1] + v1[2] * av[2]);
+            q[0] = (float)au[0], q[1] = (float)au[1], q[2] = (float)au[2], q[3] = (float)au0;
+            q[4] = (float)av[0], q[5] = (float)av[1], q[6] = (float)av[2], q[7] = (float)av0;
+            for (int k = 0; k < 8; k++)
+              if (!std::isfinite(q[k])) Rr = 0;
+            // The kernel evaluates the maps in fp32: a sliver's are ill-conditioned.  The cells are computed 5 % larger
+            // than they are; keep the error of u * R, v * R below 4 % of a cell (R = 1 needs no coordinates at all).
+            const double err = 4e-7 * std::fmax((std::fabs(au[0]) + std::fabs(au[1]) + std::fabs(au[2])) * pmax + std::fabs(au0),
+                                                (std::fabs(av[0]) + std::fabs(av[1]) + std::fabs(av[2])) * pmax + std::fabs(av0));
+            if (Rr > 1u && err * Rr > 0.04) Rr = (uint32_t)std::fmax(1.0, std::floor(0.04 / err));
+          }
+          const uint32_t first = (uint32_t)total;
+          memcpy(&q[8], &Rr, 4), memcpy(&q[9], &first, 4);
+          float* g = &geo[12 * (size_t)t];
+          g[0] = v1[0], g[1] = v1[1], g[2] = v1[2], memcpy(&g[3], &Rr, 4);
+          g[4] = e1[0], g[5] = e1[1], g[6] = e1[2], memcpy(&g[7], &first, 4);
+          g[8] = e2[0], g[9] = e2[1], g[10] = e2[2], g[11] = 0.f;
+          total += (uint64_t)Rr * Rr;
         }
-        const uint32_t first = (uint32_t)cell_tri.size();
-        memcpy(&q[8], &Rr, 4), memcpy(&q[9], &first, 4);
-        q[10] = q[11] = 0.f;
-        float* g = &geo[12 * (size_t)t];
-        g[0] = v1[0], g[1] = v1[1], g[2] = v1[2], memcpy(&g[3], &Rr, 4);
-        g[4] = e1[0], g[5] = e1[1], g[6] = e1[2], memcpy(&g[7], &first, 4);
-        g[8] = e2[0], g[9] = e2[1], g[10] = e2[2], g[11] = 0.f;
-        cell_tri.insert(cell_tri.end(), (size_t)Rr * Rr, t);
+        if (total > (1ull << 26)) continue;
+        cell_tri.reserve((size_t)total);
+        for (uint32_t t = 0; t < nt; t++) {
+          uint32_t Rr;
+          memcpy(&Rr, &recv[12 * (size_t)t + 8], 4);
+          cell_tri.insert(cell_tri.end(), (size_t)Rr * Rr, t);
+        }
+        break;
       }
       put(&s->dev.off_recv, recv.data(), recv.size() * 4);
       s->n_cells = (uint32_t)cell_tri.size();

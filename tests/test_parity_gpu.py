@@ -345,6 +345,67 @@ def test_random_scenes_scaled_and_translated(scale, seed):
     compare(cfg, flat, ((13 * seed) % 100, (7 * seed) % 80, 56, 40))
 
 
+def room_scene(seed, cfg):
+    """A floor and a back wall of two wall-sized triangles each (receiver grids of the full 256 x 256), a big sliver, a
+    degenerate triangle, small occluders hovering 0.002 .. 0.05 above both surfaces, two spheres resting on the floor;
+    lights: one overhead, one grazing the floor (0.01 above its plane), one 0.03 in front of the wall."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.scene import FlatScene
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    sh, sd = cfg.height / cfg.width, 1.0
+    yf, zw = sh * 0.9, 0.9  # floor plane y = yf (the camera looks along +z, y grows downwards), wall plane z = zw
+    v1, e1, e2 = [], [], []
+    def quad(o, a, b):
+        v1.extend([o, o + a + b]); e1.extend([a, -a]); e2.extend([b, -b])
+    quad(np.array([0.0, yf, 0.0]), np.array([1.0, 0, 0]), np.array([0, 0, zw]))      # floor
+    quad(np.array([0.0, 0.0, zw]), np.array([1.0, 0, 0]), np.array([0, yf, 0.0]))     # back wall
+    v1.append(np.array([0.1, yf - 0.2, 0.2])); e1.append(np.array([0.8, 0.0, 0.3])); e2.append(np.array([0.8, 0.002, 0.3005]))  # big sliver
+    v1.append(np.array([0.5, 0.3, 0.5])); e1.append(np.array([0.1, 0.0, 0.0])); e2.append(np.array([0.2, 0.0, 0.0]))           # degenerate
+    n_occ = 160
+    for k in range(n_occ):
+        s = rng.uniform(0.01, 0.06)
+        a, b = rng.normal(0, s, 3), rng.normal(0, s, 3)
+        h = rng.uniform(0.002, 0.05)
+        if k % 2:   # above the floor
+            o = np.array([rng.uniform(0.1, 0.9), yf - h - abs(a[1]) - abs(b[1]), rng.uniform(0.15, zw - 0.1)])
+        else:       # in front of the wall
+            o = np.array([rng.uniform(0.1, 0.9), rng.uniform(0.1, yf - 0.1), zw - h - abs(a[2]) - abs(b[2])])
+        v1.append(o); e1.append(a); e2.append(b)
+    v1, e1, e2 = (np.asarray(x, f32) for x in (v1, e1, e2))
+    nrm = np.cross(e1, e2)
+    nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)).astype(f32)
+    nrm[0:2] = [0, -1, 0]; nrm[2:4] = [0, 0, -1]
+    mats = np.asarray([[0.8, 0.7, 0.6, 0.0, 0.3, 0, 0, 0, 0], [0.5, 0.75, 0.75, 0.0, 0.0, 0, 0, 0, 0],
+                       [0.9, 0.3, 0.3, 0.0, 0.5, 0, 0, 0, 0], [0.75, 0.9, 0.8, 0.0, 0.7, 1.3, 0.7, 0, 1]], f32)
+    tm = np.zeros(len(v1), np.uint32); tm[2:4] = 1; tm[4:] = 2; tm[6::7] = 3   # every 7th occluder is glass
+    sc = np.asarray([[0.3, yf - 0.08, 0.5], [0.7, yf - 0.05, 0.35]], f32); sr = np.asarray([0.08, 0.05], f32)
+    lights = np.asarray([[0.5, 0.05, 0.3, 1, 1, 1, 0.8], [0.15, yf - 0.01, 0.25, 1.0, 0.8, 0.6, 0.5], [0.6, 0.35, zw - 0.03, 0.6, 0.8, 1.0, 0.5]], f32)
+    return FlatScene(sc, (sr * sr).astype(f32), (1 / sr).astype(f32), np.asarray([0, 3], np.uint32), v1, e1, e2, nrm, tm, mats, lights)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_receiver_flags_on_walls_with_close_occluders_and_grazing_lights(seed):
+    """Receiver flags (rt_flags_kernel: a wavefront whose hit points all lie in cells no triangle can shadow skips the
+    candidate walk): a room built to stress them -- wall-sized receivers, occluders millimetres above them, a light
+    grazing the floor, a light close to the wall, a sliver and a degenerate triangle -- full frame with the flags against
+    the frame without them (hit ids equal, colours within the arrival-path rounding), and windows against the oracle."""
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], width_override=320, height_override=256,
+                                     n_cloud_sets=32, cloud_seed=seed)
+    flat = room_scene(seed, cfg)
+    a0, p0, s0 = gpu_render(cfg, flat)
+    a1, p1, s1 = gpu_render(cfg, flat, no_receiver_flags=1)
+    assert np.array_equal(p0["hit_id"], p1["hit_id"])
+    assert (p0["hit_id"] >= 0).mean() > 0.3
+    assert np.abs(p0["rgb"] - p1["rgb"]).max() <= 4e-6, np.abs(p0["rgb"] - p1["rgb"]).max()
+    assert s0["rays_shadow"] == s1["rays_shadow"] and s0["pixels_written"] == s1["pixels_written"]
+    ids = p0["hit_id"].reshape(cfg.height, cfg.width)
+    for first in (flat.n_spheres, flat.n_spheres + 2):   # a window centred on the floor's hits, one on the wall's
+        ys, xs = np.nonzero((ids == first) | (ids == first + 1))
+        assert ys.size > 2000
+        x0 = int(np.clip(np.median(xs) - 20, 0, cfg.width - 40)), int(np.clip(np.median(ys) - 12, 0, cfg.height - 24))
+        compare(cfg, flat, (x0[0], x0[1], 40, 24))
+
+
 def test_more_than_32_spheres():
     """The per-(wavefront, light) sphere mask and the lane-parallel sphere pre-selection cover spheres 0..31; the
     ones beyond are tested unconditionally.  40 spheres, soft shadows, secondary rays."""
