@@ -70,7 +70,7 @@ void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
   for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb,
-                    &s->aux_id, &s->aux_t, &s->flag_geo, &s->flag_cell_tri, &s->flags})
+                    &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags})
     b->release();
   delete s;
 }
@@ -203,8 +203,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     put(&s->dev.off_tri_isect, isect.data(), isect.size() * 4);
     {
-      // Receiver cells: every triangle carries an R x R grid over its (u, v) coordinates, cells of about 1/256 of the
-      // scene's diagonal (R = 1 for the small triangles of a mesh, up to 256 for a wall).  The flags themselves depend on
+      // Receiver cells: every triangle carries an R x R grid over its (u, v) coordinates, cells of about 1/1024 of the
+      // scene's diagonal (R = 1 for the small triangles of a mesh, up to 1024 for a wall).  The flags themselves depend on
       // the light clouds and are computed by rt_flags_kernel when a frame first needs them (prepare()).
       double diag2 = 0.0, pmax = 0.0;
       for (int a = 0; a < 3; a++) {
@@ -212,11 +212,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         pmax = std::fmax(pmax, std::fmax(std::fabs((double)s->aabb_lo[a]), std::fabs((double)s->aabb_hi[a])));
       }
       std::vector<float> recv(12 * (size_t)nt), geo(12 * (size_t)nt);
-      std::vector<uint32_t> cell_tri;
-      // (a scene of many wall-sized triangles: coarser cells until the tables stay below 2^26 cells)
-      for (double cell = std::sqrt(diag2) / 256.0;; cell *= 2.0) {
-        cell_tri.clear();
-        uint64_t total = 0;
+      uint64_t total = 0;
+      // (a scene of many wall-sized triangles: coarser cells until the flags stay below 2^26 cells = 128 MiB)
+      for (double cell = std::sqrt(diag2) / 1024.0;; cell *= 2.0) {
+        total = 0;
         for (uint32_t t = 0; t < nt; t++) {
           const float *v1 = d->tri_v1 + 3 * (size_t)t, *e1 = d->tri_e1 + 3 * (size_t)t, *e2 = d->tri_e2 + 3 * (size_t)t;
           const double n[3] = {(double)e1[1] * e2[2] - (double)e1[2] * e2[1], (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
@@ -228,7 +227,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
           float* q = &recv[12 * (size_t)t];
           for (int k = 0; k < 12; k++) q[k] = 0.f;
           if (nn > 0.0 && std::isfinite(nn) && cell > 0.0) {
-            Rr = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(std::sqrt(std::fmax(l1, l2)) / cell)));
+            Rr = (uint32_t)std::fmin(1024.0, std::fmax(1.0, std::ceil(std::sqrt(std::fmax(l1, l2)) / cell)));
             // u = (p - v1) . (e2 x n) / n.n,  v = (p - v1) . (n x e1) / n.n
             const double au[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
             const double av[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
@@ -251,20 +250,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
           g[8] = e2[0], g[9] = e2[1], g[10] = e2[2], g[11] = 0.f;
           total += (uint64_t)Rr * Rr;
         }
-        if (total > (1ull << 26)) continue;
-        cell_tri.reserve((size_t)total);
-        for (uint32_t t = 0; t < nt; t++) {
-          uint32_t Rr;
-          memcpy(&Rr, &recv[12 * (size_t)t + 8], 4);
-          cell_tri.insert(cell_tri.end(), (size_t)Rr * Rr, t);
-        }
-        break;
+        if (total <= (1ull << 26)) break;
       }
       put(&s->dev.off_recv, recv.data(), recv.size() * 4);
-      s->n_cells = (uint32_t)cell_tri.size();
+      s->n_cells = (uint32_t)total;
       if (s->n_cells) {
         if ((rc = upload(s->flag_geo, geo.data(), geo.size() * 4)) != RT_OK) return bail(rc);
-        if ((rc = upload(s->flag_cell_tri, cell_tri.data(), cell_tri.size() * 4)) != RT_OK) return bail(rc);
         if ((rc = s->flags.ensure((size_t)s->n_cells * 2 + 64)) != RT_OK) return bail(rc);
       }
     }
@@ -543,7 +534,6 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
         RtDevParams B = *P;
         B.flag_out = (uint16_t*)s->flags.p;
         B.flag_geo = (const float4*)s->flag_geo.p;
-        B.flag_cell_tri = (const uint32_t*)s->flag_cell_tri.p;
         B.n_cells = s->n_cells;
         hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));

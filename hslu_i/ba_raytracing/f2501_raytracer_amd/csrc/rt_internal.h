@@ -116,7 +116,6 @@ struct RtDevParams {
   const uint16_t* recv_flags;
   uint16_t* flag_out;
   const float4* flag_geo;         // canonical triangles: {v1, bits(R)} {e1, bits(first cell)} {e2, 0}
-  const uint32_t* flag_cell_tri;  // cell -> canonical triangle
   uint32_t n_cells;
   uint32_t max_depth_reflection, max_depth_refraction;
   uint32_t win_x0, win_y0, win_w, win_h;

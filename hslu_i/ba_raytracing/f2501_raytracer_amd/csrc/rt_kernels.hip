@@ -2244,7 +2244,16 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
 __global__ __launch_bounds__(256) void rt_flags_kernel(RtDevScene sc, RtDevParams P) {
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
   const bool have = c < P.n_cells;
-  const uint32_t t = have ? P.flag_cell_tri[c] : 0u;
+  // the triangle that owns cell c: the last one whose first cell is <= c (triangles without cells share their successor's)
+  uint32_t t = 0u;
+  if (have) {
+    uint32_t lo = 0u, hi = sc.n_triangles;  // invariant: first(lo) <= c, first(hi) > c (first(n) = n_cells)
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (__float_as_uint(P.flag_geo[3u * mid + 1u].w) <= c) lo = mid; else hi = mid;
+    }
+    t = lo;
+  }
   const float4 g0 = P.flag_geo[3u * t], g1 = P.flag_geo[3u * t + 1u], g2 = P.flag_geo[3u * t + 2u];
   const uint32_t R = __float_as_uint(g0.w), first = __float_as_uint(g1.w);
   const uint32_t local = have ? c - first : 0u;
