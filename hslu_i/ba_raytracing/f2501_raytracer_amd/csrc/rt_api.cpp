@@ -214,8 +214,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
       std::vector<float> recv(12 * (size_t)nt), geo(12 * (size_t)nt);
       uint64_t total = 0;
       // (a scene of many wall-sized triangles: coarser cells until the flags stay below 2^26 cells = 128 MiB)
+      double cell_used = 0.0;
       for (double cell = std::sqrt(diag2) / 1024.0;; cell *= 2.0) {
         total = 0;
+        cell_used = cell;
         for (uint32_t t = 0; t < nt; t++) {
           const float *v1 = d->tri_v1 + 3 * (size_t)t, *e1 = d->tri_e1 + 3 * (size_t)t, *e2 = d->tri_e2 + 3 * (size_t)t;
           const double n[3] = {(double)e1[1] * e2[2] - (double)e1[2] * e2[1], (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
@@ -253,6 +255,20 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (total <= (1ull << 26)) break;
       }
       put(&s->dev.off_recv, recv.data(), recv.size() * 4);
+      s->n_tri_cells = (uint32_t)total;
+      {
+        // sphere receivers: a cube map of directions per sphere, cells of about the same size on its surface
+        std::vector<uint32_t> srecv(2 * (size_t)ns + 2, 0u);
+        for (uint32_t i = 0; i < ns; i++) {
+          const double r = std::sqrt(std::fabs((double)d->sphere_r_sq[i]));
+          uint32_t Rs = 0;
+          if (std::isfinite(r) && r > 0.0 && cell_used > 0.0) Rs = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(1.5708 * r / cell_used)));
+          if (total + 6ull * Rs * Rs > (1ull << 27)) Rs = 0;
+          srecv[2 * i] = Rs, srecv[2 * i + 1] = (uint32_t)total;
+          total += 6ull * Rs * Rs;
+        }
+        put(&s->dev.off_srecv, srecv.data(), srecv.size() * 4);
+      }
       s->n_cells = (uint32_t)total;
       if (s->n_cells) {
         if ((rc = upload(s->flag_geo, geo.data(), geo.size() * 4)) != RT_OK) return bail(rc);
@@ -535,6 +551,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
         B.flag_out = (uint16_t*)s->flags.p;
         B.flag_geo = (const float4*)s->flag_geo.p;
         B.n_cells = s->n_cells;
+        B.n_tri_cells = s->n_tri_cells;
         hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));
         memcpy(s->flags_key, key, sizeof(key));

@@ -78,7 +78,7 @@ struct rt_scene {
   float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
   // receiver flags (rt_flags_kernel): cell tables built with the scene, flags rebuilt when the beam constants change
   DevBuf flag_geo, flags;
-  uint32_t n_cells = 0;
+  uint32_t n_cells = 0, n_tri_cells = 0;
   float flags_key[8] = {-1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // beam_delta, eps, cloud centre: what the flags were built for
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
 };

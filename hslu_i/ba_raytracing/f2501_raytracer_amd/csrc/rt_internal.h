@@ -83,6 +83,8 @@ struct RtDevScene {
   // receiver records, canonical triangle order, 48 B: {Au, au0} {Av, av0} {bits(R), bits(first cell), 0, 0} -- barycentric
   // coordinates of a hit point p are u = Au.p + au0, v = Av.p + av0; the triangle's R x R cells start at `first cell`
   uint32_t off_recv;
+  // sphere receivers: {Rs, first cell} per sphere -- a cube map of 6 x Rs x Rs cells over the directions from its centre
+  uint32_t off_srecv;
   uint32_t n_thr;
   uint32_t n_spheres, n_triangles, n_lights, n_nodes;
   uint32_t n_slots;  // triangle references in leaf order (>= n_triangles with split clipping)
@@ -117,6 +119,7 @@ struct RtDevParams {
   uint16_t* flag_out;
   const float4* flag_geo;         // canonical triangles: {v1, bits(R)} {e1, bits(first cell)} {e2, 0}
   uint32_t n_cells;
+  uint32_t n_tri_cells;  // cells [0, n_tri_cells) belong to triangles, the rest to spheres
   uint32_t max_depth_reflection, max_depth_refraction;
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tile_size, n_ranks, rank;

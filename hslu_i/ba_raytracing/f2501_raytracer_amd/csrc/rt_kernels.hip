@@ -699,7 +699,7 @@ struct CandList {
 // has no candidate triangle and skips the walk.
 struct FatBeam {
   float r;       // every point of the cell lies within r (1-norm) of the beam origin
-  V3 pt[4];      // the cell's corners
+  V3 pt[8];      // the cell's corners: a triangle's cell twice, the inner and outer corners of a sphere's
 };
 enum { COLLECT_OWN = 0, COLLECT_FLAGS = 1 };
 
@@ -802,7 +802,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       const float rhs = t_push * (ad - dslack);
       rej = ~0ull;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < 8; k++) {
         const V3 bk = mk(q0.x, q0.y, q0.z) - fb->pt[k];
         const float xk = __uint_as_float(__float_as_uint(dot(x, bk)) ^ sgn);
         const float sk = __builtin_fmaf(fabsf(x.x), fabsf(bk.x), __builtin_fmaf(fabsf(x.y), fabsf(bk.y), fabsf(x.z) * fabsf(bk.z)));
@@ -1385,6 +1385,19 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       // (cells beyond the hypotenuse carry no flags; the cells are computed 5 % larger than they are, which covers the
       // rounding of u and v)
       if (rr.x != 0u && ci + cj < rr.x) rflags = P.recv_flags[rr.y + ci + rr.x * cj];
+    } else if (P.recv_flags && hit && h.id >= 0) {
+      // a sphere: the cell of the direction centre -> p in the sphere's cube map (face = largest component)
+      const uint2 sr = vload<uint2>(sc, sc.off_srecv + (uint32_t)h.id * 8u);  // {Rs, first cell}
+      const float4 sp = vload<float4>(sc, sc.off_spheres + (uint32_t)h.id * 16u);
+      const V3 dd = sf.p - mk(sp.x, sp.y, sp.z);
+      const float ax = fabsf(dd.x), ay = fabsf(dd.y), az = fabsf(dd.z);
+      const bool mx = ax >= ay && ax >= az, my = !mx && ay >= az;
+      const float dm = mx ? dd.x : (my ? dd.y : dd.z), du = mx ? dd.y : (my ? dd.z : dd.x), dv = mx ? dd.z : (my ? dd.x : dd.y);
+      const uint32_t face = (mx ? 0u : (my ? 2u : 4u)) + (dm < 0.0f ? 1u : 0u);
+      const float inv = __builtin_amdgcn_rcpf(fmaxf(fabsf(dm), 1e-30f)), Rf = (float)sr.x;
+      const uint32_t ci = (uint32_t)fminf(fmaxf((__builtin_fmaf(du, inv, 1.0f)) * 0.5f * Rf, 0.0f), Rf - 1.0f);
+      const uint32_t cj = (uint32_t)fminf(fmaxf((__builtin_fmaf(dv, inv, 1.0f)) * 0.5f * Rf, 0.0f), Rf - 1.0f);
+      if (sr.x != 0u) rflags = P.recv_flags[sr.y + (face * sr.x + cj) * sr.x + ci];
     }
     stash[threadIdx.x + 10 * 256] = __uint_as_float(rflags);
   }
@@ -2244,34 +2257,80 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
 __global__ __launch_bounds__(256) void rt_flags_kernel(RtDevScene sc, RtDevParams P) {
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
   const bool have = c < P.n_cells;
-  // the triangle that owns cell c: the last one whose first cell is <= c (triangles without cells share their successor's)
-  uint32_t t = 0u;
-  if (have) {
-    uint32_t lo = 0u, hi = sc.n_triangles;  // invariant: first(lo) <= c, first(hi) > c (first(n) = n_cells)
+  FatBeam fb;
+  V3 pm = mk(0.0f, 0.0f, 0.0f);
+  bool active = false;
+  if (have && c < P.n_tri_cells) {
+    // ---- a cell of a triangle: the parallelogram [i, i+1] x [j, j+1] / R of its (u, v) coordinates -------------------
+    // the triangle that owns cell c: the last one whose first cell is <= c (triangles without cells share their successor's)
+    uint32_t lo = 0u, hi = sc.n_triangles;  // invariant: first(lo) <= c, first(hi) > c (first(n) = n_tri_cells)
     while (hi - lo > 1u) {
       const uint32_t mid = (lo + hi) >> 1;
       if (__float_as_uint(P.flag_geo[3u * mid + 1u].w) <= c) lo = mid; else hi = mid;
     }
-    t = lo;
+    const uint32_t t = lo;
+    const float4 g0 = P.flag_geo[3u * t], g1 = P.flag_geo[3u * t + 1u], g2 = P.flag_geo[3u * t + 2u];
+    const uint32_t R = __float_as_uint(g0.w), first = __float_as_uint(g1.w);
+    const uint32_t local = c - first;
+    const uint32_t j = R ? local / R : 0u, i = local - j * R;
+    active = R != 0u && i + j < R;  // (cells beyond the hypotenuse are never looked up)
+    const V3 v1 = mk(g0.x, g0.y, g0.z), e1 = mk(g1.x, g1.y, g1.z), e2 = mk(g2.x, g2.y, g2.z);
+    const float inv_r = R ? 1.0f / (float)R : 0.0f;
+    // the cell, 5 % larger than it is on every side (a hit point's computed (u, v) may round across a cell border)
+    const float u0 = ((float)i - 0.05f) * inv_r, u1 = ((float)i + 1.05f) * inv_r, w0 = ((float)j - 0.05f) * inv_r, w1 = ((float)j + 1.05f) * inv_r;
+    fb.pt[0] = v1 + e1 * u0 + e2 * w0;
+    fb.pt[1] = v1 + e1 * u1 + e2 * w0;
+    fb.pt[2] = v1 + e1 * u0 + e2 * w1;
+    fb.pt[3] = v1 + e1 * u1 + e2 * w1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) fb.pt[4 + k] = fb.pt[k];
+    pm = v1 + e1 * (((float)i + 0.5f) * inv_r) + e2 * (((float)j + 0.5f) * inv_r);
+  } else if (have) {
+    // ---- a cell of a sphere: a patch of its cube map of directions.  The patch lies in the frustum of the cone through
+    // its four corner directions between the tangent plane at the patch centre (outer corners, r / cos) and the parallel
+    // plane through its lowest corner (inner corners, r cos_min / cos): 8 points whose hull contains the patch ----------
+    uint32_t k = 0u, Rs = 0u, first = 0u;
+    for (uint32_t q = 0; q < sc.n_spheres; q++) {
+      const uint2 sr = vload<uint2>(sc, sc.off_srecv + q * 8u);
+      if (sr.x != 0u && c >= sr.y && c < sr.y + 6u * sr.x * sr.x) k = q, Rs = sr.x, first = sr.y;
+    }
+    if (Rs != 0u) {
+      active = true;
+      const float4 sp = vload<float4>(sc, sc.off_spheres + k * 16u);
+      const float rad = vload<float>(sc, sc.off_sphere_rad + k * 4u);  // (upper bound of the radius)
+      const uint32_t local = c - first, face = local / (Rs * Rs), rem = local - face * Rs * Rs, j = rem / Rs, i = rem - j * Rs;
+      const float inv_r = 2.0f / (float)Rs;
+      const float a0 = fmaxf(((float)i - 0.05f) * inv_r - 1.0f, -1.1f), a1 = fminf(((float)i + 1.05f) * inv_r - 1.0f, 1.1f);
+      const float b0 = fmaxf(((float)j - 0.05f) * inv_r - 1.0f, -1.1f), b1 = fminf(((float)j + 1.05f) * inv_r - 1.0f, 1.1f);
+      const uint32_t m = face >> 1;
+      const float sgn = (face & 1u) ? -1.0f : 1.0f;
+      auto dir = [&](float a, float b) {  // component m = sign, (m + 1) % 3 = a, (m + 2) % 3 = b; normalised
+        const V3 d = m == 0u ? mk(sgn, a, b) : (m == 1u ? mk(b, sgn, a) : mk(a, b, sgn));
+        return d * __builtin_amdgcn_rsqf(dot(d, d));
+      };
+      const V3 ctr = mk(sp.x, sp.y, sp.z);
+      const V3 uc = dir(0.5f * (a0 + a1), 0.5f * (b0 + b1));
+      const V3 uk[4] = {dir(a0, b0), dir(a1, b0), dir(a0, b1), dir(a1, b1)};
+      float cmin = 1.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cmin = fminf(cmin, dot(uk[q], uc));
+      cmin = fmaxf(cmin * 0.9999f, 0.1f);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float cq = fmaxf(dot(uk[q], uc), 0.1f);
+        fb.pt[q] = ctr + uk[q] * (rad * cmin * 0.9999f * __builtin_amdgcn_rcpf(cq));      // inner
+        fb.pt[4 + q] = ctr + uk[q] * (rad * 1.0001f * __builtin_amdgcn_rcpf(cq));          // outer (tangent plane)
+      }
+      pm = ctr + uc * rad;
+    }
   }
-  const float4 g0 = P.flag_geo[3u * t], g1 = P.flag_geo[3u * t + 1u], g2 = P.flag_geo[3u * t + 2u];
-  const uint32_t R = __float_as_uint(g0.w), first = __float_as_uint(g1.w);
-  const uint32_t local = have ? c - first : 0u;
-  const uint32_t j = R ? local / R : 0u, i = local - j * R;
-  const bool active = have && R != 0u && i + j < R;  // (cells beyond the hypotenuse are never looked up)
-  const V3 v1 = mk(g0.x, g0.y, g0.z), e1 = mk(g1.x, g1.y, g1.z), e2 = mk(g2.x, g2.y, g2.z);
-  const float inv_r = R ? 1.0f / (float)R : 0.0f;
-  // the cell, 5 % larger than it is on every side (a hit point's computed (u, v) may round across a cell border)
-  const float u0 = ((float)i - 0.05f) * inv_r, u1 = ((float)i + 1.05f) * inv_r, w0 = ((float)j - 0.05f) * inv_r, w1 = ((float)j + 1.05f) * inv_r;
-  FatBeam fb;
-  fb.pt[0] = v1 + e1 * u0 + e2 * w0;
-  fb.pt[1] = v1 + e1 * u1 + e2 * w0;
-  fb.pt[2] = v1 + e1 * u0 + e2 * w1;
-  fb.pt[3] = v1 + e1 * u1 + e2 * w1;
-  const V3 pm = v1 + e1 * (((float)i + 0.5f) * inv_r) + e2 * (((float)j + 0.5f) * inv_r);
+  if (!active) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) fb.pt[k] = pm;
+  }
   float r = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 8; k++) {
     const V3 dk = fb.pt[k] - pm;
     r = fmaxf(r, fabsf(dk.x) + fabsf(dk.y) + fabsf(dk.z));
   }
