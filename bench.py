@@ -144,8 +144,8 @@ def cpu_baseline(cfg, flat, budget_s=18.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # ~1 s of frames: enough for a GPU-busy sampler to see them
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
