@@ -444,36 +444,67 @@ struct Hit {
   int id;  // canonical object index, -1 = none
 };
 
+// State of one shadow / transmittance ray (IntersectionTest, raytracer.rs:17-106).  The reference folds every hit <= tmax
+// into `opacity = clamp(opacity - (1 - io), 0, 1)` and `filter -= absorption` in ITS object order; every decrement is
+// >= 0, so the results are max(0, 1 - sum(1 - io_i)) and 1 - sum(absorption_i) whatever the order -- up to float
+// rounding.  A BVH visits the hits in an order that depends on the other rays of the wavefront, so the sums are kept as
+// INTEGERS (2^-28 / 2^-24 fixed point): integer addition is associative, and the value a lane ends with depends on
+// its own ray alone, not on the wavefront it happened to be packed into.  Both only scale the colour (an opaque hit
+// occludes whatever the opacity was: clamp(op - 1, 0, 1) = 0 for every op <= 1).
 struct Shadow {
-  lanemask occ;  // lanes that are completely occluded (wave-uniform mask)
-  float opacity;
-  V3 filter;
+  lanemask occ;        // lanes that are completely occluded (wave-uniform mask)
+  uint32_t dec;        // sum of the hits' opacity decrements 1 - io, 2^-28 units, saturated at 1.0
+  uint32_t fr, fg, fb; // sum of the hits' absorption per channel, 2^-24 units
 };
+#define RT_SH_ONE (1u << 28)
+#define RT_SH_SCALE 268435456.0f
+#define RT_SH_INV_SCALE (1.0f / 268435456.0f)
+#define RT_FILT_SCALE 16777216.0f
+#define RT_FILT_INV_SCALE (1.0f / 16777216.0f)
+__device__ __forceinline__ void shadow_init(Shadow& S) {
+  S.occ = 0ull;
+  S.dec = 0u;
+  S.fr = S.fg = S.fb = 0u;
+}
+__device__ __forceinline__ float shadow_opacity(const Shadow& S) { return (float)(RT_SH_ONE - S.dec) * RT_SH_INV_SCALE; }
+__device__ __forceinline__ V3 shadow_filter(const Shadow& S) {
+  return mk(1.0f - (float)S.fr * RT_FILT_INV_SCALE, 1.0f - (float)S.fg * RT_FILT_INV_SCALE, 1.0f - (float)S.fb * RT_FILT_INV_SCALE);
+}
 
 // one transmissive / opaque occluder on a shadow ray, raytracer.rs:53-92, applied to the lanes in `h`
 // (predicated, outside divergent control flow, so that S.occ stays a wave-uniform mask; m is wave-uniform)
 __device__ __forceinline__ void shadow_accumulate(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
-  float io = 0.0f;
-  if (m.transmissive) io = m.opacity * (1.0f - fresnel_reflectance_air_red(m, n, -d));
+  if (!m.transmissive) {
+    S.occ |= h;  // io = 0: the decrement is 1
+    return;
+  }
+  const float io = m.opacity * (1.0f - fresnel_reflectance_air_red(m, n, -d));
   const bool on = lane_of(h);
-  const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
-  S.opacity = on ? nop : S.opacity;
-  if (!m.transmissive) S.occ |= h & wave_ballot(fabsf(nop - 0.0f) <= RT_EPS);
-  const V3 nf = S.filter - absorption(m);
-  S.filter = mk(on ? nf.x : S.filter.x, on ? nf.y : S.filter.y, on ? nf.z : S.filter.z);
+  const uint32_t di = (uint32_t)__float2uint_rn(clampf(1.0f - io, 0.0f, 1.0f) * RT_SH_SCALE);
+  const uint32_t nd = min(S.dec + di, RT_SH_ONE);
+  S.dec = on ? nd : S.dec;
+  const V3 ab = absorption(m);  // wave-uniform
+  const uint32_t ar = (uint32_t)__float2uint_rn(ab.x * RT_FILT_SCALE), ag = (uint32_t)__float2uint_rn(ab.y * RT_FILT_SCALE),
+                 abl = (uint32_t)__float2uint_rn(ab.z * RT_FILT_SCALE);
+  S.fr = on ? S.fr + ar : S.fr;
+  S.fg = on ? S.fg + ag : S.fg;
+  S.fb = on ? S.fb + abl : S.fb;
 }
 
 // same for an occluder whose material differs from lane to lane (per-lane walk, rt_hard_kernel)
 template <bool CULL>
 __device__ __forceinline__ void shadow_accumulate_lane(Shadow& S, const Mat& m, V3 n, V3 d, lanemask h) {
   if (CULL) h &= wave_ballot(m.transmissive || dot(d, n) < 0.75f);  // sphere.rs:137-151, triangle.rs:154-168
+  S.occ |= h & wave_ballot(!m.transmissive);
   const float io = m.transmissive ? m.opacity * (1.0f - fresnel_reflectance_air_red(m, n, -d)) : 0.0f;
   const bool on = lane_of(h);
-  const float nop = clampf(S.opacity - (1.0f - io), 0.0f, 1.0f);
-  S.opacity = on ? nop : S.opacity;
-  S.occ |= h & wave_ballot(!m.transmissive && fabsf(nop - 0.0f) <= RT_EPS);
-  const V3 nf = S.filter - absorption(m);
-  S.filter = mk(on ? nf.x : S.filter.x, on ? nf.y : S.filter.y, on ? nf.z : S.filter.z);
+  const uint32_t di = (uint32_t)__float2uint_rn(clampf(1.0f - io, 0.0f, 1.0f) * RT_SH_SCALE);
+  const uint32_t nd = min(S.dec + di, RT_SH_ONE);
+  S.dec = on ? nd : S.dec;
+  const V3 ab = absorption(m);
+  S.fr = on ? S.fr + (uint32_t)__float2uint_rn(ab.x * RT_FILT_SCALE) : S.fr;
+  S.fg = on ? S.fg + (uint32_t)__float2uint_rn(ab.y * RT_FILT_SCALE) : S.fg;
+  S.fb = on ? S.fb + (uint32_t)__float2uint_rn(ab.z * RT_FILT_SCALE) : S.fb;
 }
 
 struct WaveCtx {
@@ -1004,9 +1035,7 @@ template <bool CULL, bool LIST>
 __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevParams& P, WaveCtx& W,
                                              lanemask grp, V3 o, V3 d_raw, float tmax, const CandList& cand) {
   Shadow S;
-  S.occ = 0ull;
-  S.opacity = 1.0f;
-  S.filter = mk(1.0f, 1.0f, 1.0f);
+  shadow_init(S);
   V3 d = normalize_unit(d_raw, grp);  // Ray::new_with_mask re-normalises, ray.rs:52-57 (d_raw is unit up to rounding)
 #if RT_PROFILE
   RT_OPAQUE(d.x);
@@ -1036,7 +1065,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
   for (uint32_t i = 32u; i < sc.n_spheres; i++) test_sphere(i);
   if (!LIST && sc.n_triangles == 0) return S;
 #if RT_PROFILE
-  RT_OPAQUE(S.opacity);
+  RT_OPAQUE(S.dec);
 #endif
   PROF_ADD(W, 3, t_sph);
   const unsigned long long t_tri = PROF_T();
@@ -1074,7 +1103,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
       test_tri(slot, grp);
     }
 #if RT_PROFILE
-    RT_OPAQUE(S.opacity);
+    RT_OPAQUE(S.dec);
 #endif
     PROF_ADD(W, 4, t_tri);
     return S;
@@ -1164,6 +1193,59 @@ __device__ __forceinline__ Surf surface_of(const RtDevScene& sc, Hit h, V3 o, V3
 __device__ __forceinline__ uint32_t to_u8(float x) {
   float cx = fminf(fmaxf(x, 0.0f), 1.0f);
   return (uint32_t)__float2uint_rn(cx * 255.0f);
+}
+
+// ---- one light sample's colour terms ---------------------------------------------------------------------------
+// PointLight::calculate_contribution_at (light.rs:261-299) and the sample's share of calculate_lighting
+// (raytracer_renderer.rs:800-851).  ONE function for every route a (hit point, light) pair can take -- the arrival
+// loop of sets with nothing to test, the traced loops, rt_hard_kernel -- so that a sample's terms are the same bits
+// whatever the wavefront around it made the kernel do (the image does not depend on how lanes are packed into
+// wavefronts).  Everything here only scales the colour (tolerance 1e-4, measured < 4e-6): the direction and distance
+// to the light come from one v_rsq of |ltp|^2 (the shadow ray itself is set up with the exact sequences by its caller).
+// Two exact identities of the reference are used to drop work: `cosi = (ltp . n) / (|ltp| + EPS)` is `diff = n . ld` up
+// to a factor 1 + EPS/|ltp| (ld = ltp / |ltp|), and its `cosi > 0` selects are implied by the `diff > 0` gate of the sum.
+struct LightTerms {
+  V3 mLc;    // surface colour^2 x light colour / filter (the reference multiplies the surface colour in twice)
+  float lf;  // diff * intensity * opacity: the sample's share of `direct`
+  float sf;  // intensity * opacity * specular lobe: its share of `specular`
+  bool lit;  // diff > 0
+};
+// FILTERED = false: the shadow ray is known to arrive untouched (opacity 1, filter 1); an untouched FILTERED sample
+// gives the same bits (x * 1.0f and x * v_rcp(1.0f) are x).
+template <bool FILTERED>
+__device__ __forceinline__ LightTerms light_sample_terms(V3 n, V3 view, V3 mmc_lc, float lI, float mshin, bool has_spec, V3 ltp,
+                                                         const Shadow& S) {
+  LightTerms T;
+  const float l2 = dot(ltp, ltp);
+  const float rs = __builtin_amdgcn_rsqf(l2);
+  const V3 ld = ltp * rs;
+  const float dist = l2 * rs;        // |ltp| (+ EPS in the reference: below the colour tolerance by three orders)
+  const float diff = dot(n, ld);     // = cosi
+  // att = 0.95 (EPS + dist + dist^2); (tanh(att) + 1) / 2 = 1 / (1 + exp(-2 att)): one exp2 and one rcp, already inside
+  // [0, 1]; the 0.95 and the -2 log2(e) of the exponent are one constant
+  const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dist, dist, dist) * -2.7411205779f))
+                                  : clampf((tanhf(0.95f * (RT_EPS + dist + dist * dist)) + 1.0f) / 2.0f, 0.0f, 1.0f);
+  const float cint = diff * lI * sig;
+  T.mLc = mmc_lc;
+  float opac = 1.0f;
+  if (FILTERED) {
+    const V3 f = shadow_filter(S);
+    T.mLc = mk(mmc_lc.x * __builtin_amdgcn_rcpf(f.x), mmc_lc.y * __builtin_amdgcn_rcpf(f.y), mmc_lc.z * __builtin_amdgcn_rcpf(f.z));
+    opac = shadow_opacity(S);
+  }
+  float specf = 0.0f;
+  if (has_spec) {
+    // reflected(ld, n) = ld - 2 (ld.n) n with ld.n = diff; a reflection keeps the length, and the shading normal
+    // enters only through n / |n|^2 -- the reference normalises the result, here |n| = 1 is not assumed:
+    // normalize(v) . d = (v . d) / |v|
+    const V3 rv = fma_s(n, -2.0f * diff, ld);
+    const float base = fmaxf(dot(rv, view) * __builtin_amdgcn_rsqf(dot(rv, rv)), 0.0f);
+    specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
+  }
+  T.lf = FILTERED ? diff * cint * opac : diff * cint;
+  T.sf = FILTERED ? cint * opac * specf : cint * specf;
+  T.lit = diff > 0.0f;
+  return T;
 }
 
 enum { KIND_PRIMARY = 0, KIND_REFL = 1, KIND_REFR = 2 };
@@ -1297,7 +1379,12 @@ __device__ __forceinline__ void hard_push(const RtDevParams& P, lanemask m, V3 p
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-#define RT_STASH_FIELDS 11u
+// LDS stash: [field][256 threads], one dword per lane per field.  Fields 0-10: ray state parked across the light loop;
+// STREAM kernels: 11-16 = the lane's pixel contribution as three 64-bit fixed-point sums (RT_ACC_SCALE units).
+#define RT_STASH_FIELDS 17u
+#define RT_STASH_FIX 11u
+#define RT_MAT_TRANS_BIT 0x80000000u  /* stash field 6: material row | this bit when the material is transmissive */
+__device__ __forceinline__ long long* stash_fix(float* stash) { return (long long*)(stash + RT_STASH_FIX * 256u); }
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
 // STREAM: secondary rays exist (reflections / refractions): children are queued, pixel sums go through the fixed-point
 // accumulator, hard soft-shadow pairs are deferred.  The frames without them (configs 1-3) run a kernel that does not
@@ -1317,6 +1404,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
   const uint32_t N = P.light_mult < 1u ? 1u : P.light_mult;
   const bool stream = STREAM && P.q_out != nullptr;
+  if (STREAM) {
+    long long* fx = stash_fix(stash) + threadIdx.x;
+    fx[0] = fx[256] = fx[512] = 0;
+  }
 
   const unsigned long long t_all = PROF_T();
   V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
@@ -1370,7 +1461,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   sf.n = mk(0, 0, 1);
   sf.mat = 0;
   if (hit) sf = surface_of(sc, h, r.o, d);
-  stash[threadIdx.x + 6 * 256] = __uint_as_float(sf.mat);  // the material row is simply read again after the loop (L2)
   if (N > 1) {
     // receiver flags of the cell the hit point lies in (bit l: no triangle can shadow it for light l, bit 8 + l: no sphere)
     uint32_t rflags = 0u;
@@ -1402,6 +1492,8 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     stash[threadIdx.x + 10 * 256] = __uint_as_float(rflags);
   }
   const Mat m_lit = load_mat(sc, sf.mat);
+  // the material row is simply read again after the loop (L2)
+  stash[threadIdx.x + 6 * 256] = __uint_as_float(sf.mat | (m_lit.transmissive ? RT_MAT_TRANS_BIT : 0u));
   const V3 mcolor = m_lit.color;
   const float mshin = m_lit.shininess;
 
@@ -1528,7 +1620,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       int hd, hk;
       uint32_t hmult;
       unpack_dkm(__float_as_int(st[5 * 256]), hd, hk, hmult);
-      hard_push(P, use_m, sf.p, sf.n, d, __float_as_uint(st[6 * 256]), l, __float_as_uint(st[9 * 256]),
+      hard_push(P, use_m, sf.p, sf.n, d, __float_as_uint(st[6 * 256]) & ~RT_MAT_TRANS_BIT, l, __float_as_uint(st[9 * 256]),
                 mk(st[0 * 256] * a0, st[1 * 256] * a0, st[2 * 256] * a0), hmult);
       continue;
     }
@@ -1543,40 +1635,20 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     // 1 + EPS/|ltp| (ld = ltp / |ltp|), and its `cosi > 0` selects are implied by the `diff > 0` gate of the sum.
     const V3 mc_lc = mcolor * lc;  // per light
     const V3 mmc_lc = mcolor * mc_lc;  // (the reference multiplies the surface colour in twice: contribution colour x surface colour)
-    auto add_light = [&](auto filtered_tag, V3 ltp, V3 ld, float lmag, const Shadow& S, lanemask reach_m) {
+    // this light's share of `direct` and `specular`, summed over its samples in sample order from zero (the same chain
+    // rt_hard_kernel runs for a deferred pair)
+    V3 dl = mk(0.0f, 0.0f, 0.0f), ds = mk(0.0f, 0.0f, 0.0f);
+    auto add_light = [&](auto filtered_tag, V3 ltp, const Shadow& S, lanemask reach_m) {
       constexpr bool FILTERED = decltype(filtered_tag)::value;
-      const bool reach = lane_of(reach_m);
       const unsigned long long t_l = PROF_T();
-      (void)ltp;
-      const float dist = lmag;  // |ltp| (+ EPS in the reference: below the colour tolerance by three orders)
-      const float diff = dot(sf.n, ld);  // = cosi
-      // att = 0.95 (EPS + dist + dist^2); (tanh(att) + 1) / 2 = 1 / (1 + exp(-2 att)): one exp2 and one rcp, already inside
-      // [0, 1]; the 0.95 and the -2 log2(e) of the exponent are one constant (colour-only arithmetic)
-      const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dist, dist, dist) * -2.7411205779f))
-                                      : clampf((tanhf(0.95f * (RT_EPS + dist + dist * dist)) + 1.0f) / 2.0f, 0.0f, 1.0f);
-      const float cint = diff * lI * sig;
-      // colour x light colour / filter (the filter of a ray nothing transmissive touched is 1)
-      V3 mLc = mmc_lc;
-      if (FILTERED)
-        mLc = mk(mmc_lc.x * __builtin_amdgcn_rcpf(S.filter.x), mmc_lc.y * __builtin_amdgcn_rcpf(S.filter.y), mmc_lc.z * __builtin_amdgcn_rcpf(S.filter.z));
-      float specf = 0.0f;
-      if (has_spec) {
-        // reflected(ld, n) = ld - 2 (ld.n) n with ld.n = diff; a reflection keeps the length, and the shading
-        // normal enters only through n / |n|^2 -- the reference normalises the result, here |n| = 1 is not assumed:
-        // normalize(v) . d = (v . d) / |v|
-        const V3 rv = fma_s(sf.n, -2.0f * diff, ld);
-        float base = fmaxf(dot(rv, d) * __builtin_amdgcn_rsqf(dot(rv, rv)), 0.0f);
-        specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(mshin * 512.0f, 1.0f)) : powf(base, fmaxf(mshin * 512.0f, 1.0f));
-      }
-      const float light_factor = FILTERED ? diff * cint * S.opacity : diff * cint;
-      const float spec_factor = FILTERED ? cint * S.opacity * specf : cint * specf;
-      if (reach && diff > 0.0f) {
+      const LightTerms T = light_sample_terms<FILTERED>(sf.n, d, mmc_lc, lI, mshin, has_spec, ltp, S);
+      if (lane_of(reach_m) && T.lit) {
         // (fused accumulation: colour-only, one rounding less than the reference's multiply + add)
-        light_color = fma_s(mLc, light_factor, light_color);
-        if (has_spec) spec_color = fma_s(lc, spec_factor, spec_color);
+        dl = fma_s(T.mLc, T.lf, dl);
+        if (has_spec) ds = fma_s(lc, T.sf, ds);
       }
 #if RT_PROFILE
-      RT_OPAQUE(light_color.x);
+      RT_OPAQUE(dl.x);
 #endif
       PROF_ADD(W, 5, t_l);
     };
@@ -1604,15 +1676,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       // known to arrive, so their origin / length / re-normalised direction (3 IEEE sqrt, 2 IEEE div per
       // sample) are not needed; what is left of ld and |ltp| only scales the colour
       Shadow S;
-      S.occ = 0ull;
-      S.opacity = 1.0f;
-      S.filter = mk(1.0f, 1.0f, 1.0f);
+      shadow_init(S);
       for (uint32_t j = 0; j < N; j++) {
         const V3 ltp = light_position(j) - sf.p;
-        const float l2 = dot(ltp, ltp);
-        const float rs = __builtin_amdgcn_rsqf(l2);
         WSTAT(W.s_passes++);
-        add_light(std::false_type{}, ltp, ltp * rs, l2 * rs, S, use_m);
+        add_light(std::false_type{}, ltp, S, use_m);
       }
     } else {
       auto traced_samples = [&](auto list_tag) {
@@ -1622,8 +1690,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #endif
           const V3 lp = light_position(j);
           const V3 ltp = lp - sf.p;
-          const float lmag = mag(ltp);
-          const V3 ld = ltp * exact_rcp(lmag);  // normalize(ltp)
+          const V3 ld = ltp * exact_rcp(mag(ltp));  // normalize(ltp): the shadow ray's geometry is exact
           const V3 so = sf.p + ld * epsv;
           const float tmax = mag(lp - so);
           const Shadow S = shadow_ray<CULL, decltype(list_tag)::value>(sc, P, W, use_m, so, ld, tmax, cand);
@@ -1631,10 +1698,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
 #if RT_PROFILE == 3
           set_occ += (uint32_t)__popcll(use_m & S.occ);
           set_tot += (uint32_t)__popcll(use_m);
-          set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.opacity < 1.0f));
+          set_filt += (uint32_t)__popcll(reach_m & wave_ballot(S.dec != 0u));
 #endif
           if (!reach_m) continue;
-          add_light(std::true_type{}, ltp, ld, lmag, S, reach_m);
+          add_light(std::true_type{}, ltp, S, reach_m);
         }
       };
       // (decided once per light: per-sample uniform branches cost issue slots and mask registers)
@@ -1642,6 +1709,26 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         traced_samples(std::true_type{});
       else
         traced_samples(std::false_type{});
+    }
+    // this light's share of the node's own terms (:251-257: transmissive ? specular : direct + specular)
+    if (STREAM) {
+      // Streaming kernels: every (hit point, light) share reaches the pixel as its own fixed-point term W * atten * own_l --
+      // the term rt_hard_kernel adds for a pair that was deferred to it -- so the pixel sum is the same integer
+      // whichever route the pair took.
+      uint32_t tix = threadIdx.x;
+      RT_OPAQUE(tix);
+      float* st = stash + tix;
+      const float a0 = st[3 * 256];
+      const V3 Wa = mk(st[0 * 256] * a0, st[1 * 256] * a0, st[2 * 256] * a0);
+      const bool Tm = (__float_as_uint(st[6 * 256]) & RT_MAT_TRANS_BIT) != 0u;
+      const V3 c = Wa * (Tm ? ds : (dl + ds));
+      long long* fx = stash_fix(stash) + tix;
+      fx[0] += __float2ll_rn(c.x * RT_ACC_SCALE);
+      fx[256] += __float2ll_rn(c.y * RT_ACC_SCALE);
+      fx[512] += __float2ll_rn(c.z * RT_ACC_SCALE);
+    } else {
+      light_color = light_color + dl;
+      spec_color = spec_color + ds;
     }
 #if RT_PROFILE == 3  // outcome of the (wavefront, light) sets that had something to test
     if (!nothing && set_tot) {
@@ -1669,7 +1756,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     a = st[3 * 256];
     n_start = st[4 * 256];
     unpack_dkm(__float_as_int(st[5 * 256]), depth, kind, out.mult);
-    uint32_t mat_row = __float_as_uint(st[6 * 256]);
+    uint32_t mat_row = __float_as_uint(st[6 * 256]) & ~RT_MAT_TRANS_BIT;
     RT_OPAQUE(mat_row);  // keeps hipcc from carrying the row's addresses through the loop (in scratch)
     m = load_mat(sc, mat_row);
     out.t = st[7 * 256];
@@ -1679,12 +1766,22 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   }
   (void)kind;
   V3 ambient = (m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient;
-  V3 direct = (ambient + light_color) * a;  // :206-209
-  V3 spec = spec_color * a;
-
   // own terms of this node (:251-257): transmissive ? spec : direct + spec
   const bool T = m.transmissive;
-  if (hit) {
+  if (STREAM) {
+    // the lights' shares are already in the fixed-point sums; the ambient term (part of `direct`) joins them
+    if (hit && !T) {
+      const V3 c = mk(Wt.x * a, Wt.y * a, Wt.z * a) * ambient;
+      uint32_t tix = threadIdx.x;
+      RT_OPAQUE(tix);
+      long long* fx = stash_fix(stash) + tix;
+      fx[0] += __float2ll_rn(c.x * RT_ACC_SCALE);
+      fx[256] += __float2ll_rn(c.y * RT_ACC_SCALE);
+      fx[512] += __float2ll_rn(c.z * RT_ACC_SCALE);
+    }
+  } else if (hit) {
+    V3 direct = (ambient + light_color) * a;  // :206-209
+    V3 spec = spec_color * a;
     V3 own = T ? spec : (direct + spec);
     out.contrib = Wt * own;
   }
@@ -1775,6 +1872,13 @@ __device__ __forceinline__ void acc_add(const RtDevParams& P, uint32_t pix, V3 c
   atomicAdd((unsigned long long*)&a[2], (unsigned long long)(__float2ll_rn(c.z * RT_ACC_SCALE) * (long long)mult));
 }
 
+__device__ __forceinline__ void acc_add_fixed(const RtDevParams& P, uint32_t pix, long long x, long long y, long long z, uint32_t mult) {
+  long long* a = P.acc + 4 * (size_t)pix;
+  if (x) atomicAdd((unsigned long long*)&a[0], (unsigned long long)(x * (long long)mult));
+  if (y) atomicAdd((unsigned long long*)&a[1], (unsigned long long)(y * (long long)mult));
+  if (z) atomicAdd((unsigned long long*)&a[2], (unsigned long long)(z * (long long)mult));
+}
+
 // ------------------------------------------------------------------------------------------------
 // primary kernel: one thread per (pixel, DISTINCT AA sample).  The reference's sample table repeats itself
 // (raytracer_renderer.rs:107-122: [0,0], then [1,1]s; the 8 directions restart in every 8-lane chunk, :1111-1116):
@@ -1861,7 +1965,28 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   }
   __syncthreads();
   bool wrote = false;
-  if (pm2.k == 0 && pm2.on) {
+  if (STREAM && pm2.k == 0 && pm2.on) {
+    // Secondary rays are streaming: the pixel is resolved by rt_resolve_kernel from the fixed-point accumulator.  The
+    // samples' own terms are already integers (process_ray); a sample the reference casts m times adds m x its sum --
+    // exact, whatever the order, so tracing each distinct sample once changes no bit of the frame.
+    const float4* s = lds_rgbh + slot * n_thr;
+    const long long* fx = stash_fix(lds_stash) + slot * n_thr;
+    long long sx = 0, sy = 0, sz = 0;
+    bool any = false;
+    for (uint32_t u = 0; u < n_thr; u++) {
+      if (s[u].w != 0.0f) {
+        any = true;
+        const long long mu = P.weighted ? (long long)uload(&P.aa_mult[u]) : 1ll;
+        sx += fx[u] * mu, sy += fx[256u + u] * mu, sz += fx[512u + u] * mu;
+      }
+    }
+    if (any) {
+      wrote = true;
+      acc_add_fixed(P, pix, sx, sy, sz, 1u);
+      P.acc[4 * (size_t)pix + 3] = 1;
+    }
+  }
+  if (!STREAM && pm2.k == 0 && pm2.on) {
     const float4* s = lds_rgbh + slot * n_thr;
     // sample q of the reference's sum -> the thread that traced it (wave-uniform q: scalar load)
     auto src = [&](uint32_t q) { return P.weighted ? uload(&P.aa_src[q]) : q; };
@@ -1904,17 +2029,11 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
     }
     if (any) {
       wrote = true;
-      if (STREAM && P.acc) {
-        // secondary rays are streaming: the pixel is resolved by rt_resolve_kernel
-        acc_add(P, pix, color, 1u);
-        P.acc[4 * (size_t)pix + 3] = 1;
-      } else {
-        P.argb[out_index(P, pm2.gx, pm2.gy, pix)] = pack_argb(color);
-        if (P.aux_rgb) {
-          P.aux_rgb[3 * (size_t)pix + 0] = color.x;
-          P.aux_rgb[3 * (size_t)pix + 1] = color.y;
-          P.aux_rgb[3 * (size_t)pix + 2] = color.z;
-        }
+      P.argb[out_index(P, pm2.gx, pm2.gy, pix)] = pack_argb(color);
+      if (P.aux_rgb) {
+        P.aux_rgb[3 * (size_t)pix + 0] = color.x;
+        P.aux_rgb[3 * (size_t)pix + 1] = color.y;
+        P.aux_rgb[3 * (size_t)pix + 2] = color.z;
       }
     }
   }
@@ -1933,7 +2052,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
 #endif
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
-  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIX * 256];  // (no fixed-point sums without secondary rays)
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     primary_body<true, false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
@@ -1944,7 +2063,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScen
 // the same with secondary rays (children queued, accumulator, hard pairs): launched when reflections / refractions are on
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
-  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     primary_body<true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
@@ -2070,12 +2189,15 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
     if (have) r = load_queued_ray(P, (size_t)P.q_in_first + j);
   }
   RayOut out = process_ray<CULL, true, true>(sc, P, wv, have, r, lds_stash, h);
-  if (out.hit) acc_add(P, out.pix, out.contrib, out.mult);
+  if (out.hit) {
+    const long long* fx = stash_fix(lds_stash) + threadIdx.x;
+    acc_add_fixed(P, out.pix, fx[0], fx[256], fx[512], out.mult);
+  }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
-  __shared__ float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
   __shared__ unsigned long long lds_cnt[16];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     shade_body<true>(sc, P, lds_stash, lds_cnt);
@@ -2160,15 +2282,12 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
   // the shadow ray, exactly as the render kernels set it up (raytracer_renderer.rs:770-790)
   const V3 lp = mk(L0.x + cs.x, L0.y + cs.y, L0.z + cs.z);
   const V3 ltp = lp - p;
-  const float lmag = mag(ltp);
-  const V3 ld = ltp * exact_rcp(lmag);
+  const V3 ld = ltp * exact_rcp(mag(ltp));
   const V3 so = p + ld * mk(P.eps_distance, P.eps_distance, P.eps_distance);
   const float tmax = mag(lp - so);
   const V3 d = normalize_unit(ld, grp);
   Shadow S;
-  S.occ = 0ull;
-  S.opacity = 1.0f;
-  S.filter = mk(1.0f, 1.0f, 1.0f);
+  shadow_init(S);
   for (uint32_t i = 0; i < sc.n_spheres; i++) {  // spheres: few, tested by the whole wavefront one by one
     const float4 s = sload<float4>(sc, sc.off_spheres + i * 16u);
     float t = 0.0f;
@@ -2183,38 +2302,25 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
     }
   }
   shadow_tris_lane<CULL>(sc, grp, so, d, tmax, S);
-  // PointLight::calculate_contribution_at + the light's share of calculate_lighting: the same colour-only arithmetic
-  // as the render kernels' add_light (FILTERED form)
-  V3 dl = mk(0, 0, 0), ds = mk(0, 0, 0);
-  {
-    const bool reach = have && !lane_of(S.occ);
-    const float dist = lmag + RT_EPS;
-    const float diff = dot(n, ld);
-    const float sig = RT_FAST_TRANS ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(dist, dist, dist + RT_EPS) * -2.7411205779f))
-                                    : clampf((tanhf(0.95f * (RT_EPS + dist + dist * dist)) + 1.0f) / 2.0f, 0.0f, 1.0f);
-    const float cint = diff * lI * sig;
-    const V3 mc_lc = m.color * lc;
-    const V3 Lc = mk(fast_div(mc_lc.x, S.filter.x), fast_div(mc_lc.y, S.filter.y), fast_div(mc_lc.z, S.filter.z));
-    const bool has_spec = m.shininess > 0.0f;
-    float specf = 0.0f;
-    if (has_spec) {
-      const V3 rr = fast_normalize(fma_s(n, -2.0f * diff, ld));
-      const float base = fmaxf(dot(rr, view), 0.0f);
-      specf = RT_FAST_TRANS ? fast_pow01(base, fmaxf(m.shininess * 512.0f, 1.0f)) : powf(base, fmaxf(m.shininess * 512.0f, 1.0f));
-    }
-    const float light_factor = diff * cint * S.opacity, spec_factor = cint * S.opacity * specf;
-    if (reach && diff > 0.0f) {
-      dl = fma_s(m.color * Lc, light_factor, mk(0.0f, 0.0f, 0.0f));  // (the same fused form as add_light)
-      if (has_spec) ds = fma_s(lc, spec_factor, mk(0.0f, 0.0f, 0.0f));
+  // the sample's colour terms: the function the render kernels call (light_sample_terms), then the pair's chain over its
+  // N samples in sample order -- run by every lane of the pair on values fetched from the sample lanes, so that the sum
+  // is the same bits as the inline loop's
+  const bool has_spec = m.shininess > 0.0f;
+  const V3 mmc_lc = m.color * (m.color * lc);
+  const LightTerms T = light_sample_terms<true>(n, view, mmc_lc, lI, m.shininess, has_spec, ltp, S);
+  const int ok = (have && !lane_of(S.occ) && T.lit) ? 1 : 0;
+  V3 dl = mk(0.0f, 0.0f, 0.0f), ds = mk(0.0f, 0.0f, 0.0f);
+  const uint32_t first = (pw < ppw ? pw : 0u) * N;
+  for (uint32_t jj = 0; jj < N; jj++) {
+    const int src = (int)(first + jj);
+    const V3 mLc = mk(__shfl(T.mLc.x, src, 64), __shfl(T.mLc.y, src, 64), __shfl(T.mLc.z, src, 64));
+    const float lf = __shfl(T.lf, src, 64), sfv = __shfl(T.sf, src, 64);
+    if (__shfl(ok, src, 64)) {
+      dl = fma_s(mLc, lf, dl);
+      if (has_spec) ds = fma_s(lc, sfv, ds);
     }
   }
-  // sum over the pair's N lanes, fixed order (deterministic): lane j accumulates lanes j + 1, j + 2, j + 4, ...
-  V3 own = m.transmissive ? ds : (dl + ds);  // :251-257
-#pragma unroll
-  for (uint32_t off = 1; off < 64u; off <<= 1) {
-    const float ox = __shfl_down(own.x, off, 64), oy = __shfl_down(own.y, off, 64), oz = __shfl_down(own.z, off, 64);
-    if (j + off < N) own = mk(own.x + ox, own.y + oy, own.z + oz);
-  }
+  const V3 own = m.transmissive ? ds : (dl + ds);  // :251-257
   if (have && j == 0) acc_add(P, pix, Wa * own, mult);
 }
 
