@@ -12,8 +12,13 @@ ncclSend / ncclRecv group (C ABI: rt_comm_* / rt_render_gather_device) inside th
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Frames without secondary rays are enqueued on two streams alternately (two frames in flight, each into its own frame
+buffer): a launch cannot end before its longest wavefront does, and the head of the next frame fills the compute units
+that drain leaves idle.  Every timed step is a complete frame; the K steps are bracketed by barrier + synchronise.
+
 Rank 0 prints ONE JSON line.  `value` = (primary + reflection + refraction rays of one frame as the
-reference casts them, all ranks) / (max-over-ranks seconds per frame), in Mray/s.
+reference casts them, all ranks) / (max-over-ranks seconds per frame), in Mray/s; `value_traced` = the rays the GPU
+traced (repeated AA samples once) over the same time.
 """
 from __future__ import annotations
 
@@ -31,6 +36,10 @@ import numpy as np  # noqa: E402
 
 ALG_BYTES_PER_RAY = 64.0  # 32 B ray in + 32 B hit out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 flop x 2.4 GHz
+# SURVEY.md section 8(d) flop model: literal sphere test 35, literal triangle test 85; the reference scans every object
+# for every ray AND for every shadow ray (raytracer.rs:48,180), so its brute-force equivalent per ray is 35 S + 85 T
+FLOP_SPHERE, FLOP_TRIANGLE = 35.0, 85.0
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMD-32
 VALU_CYC = 2.0            # v_fma_f32 wave64 on a SIMD-32: 2 cycles (MI355X_MICROARCH.md, cycle constants)
 TRANS_CYC = 4.0           # v_exp / v_log / v_rcp / v_rsq / v_sqrt: twice the plain issue cost (8 vs 4 for one wave alone)
@@ -48,12 +57,20 @@ WORKLOADS = {
     # configs[3]
     "c4": dict(features=["high_resolution", "realistic", "extreme_quality"], model="text", scene="semesterbild",
                depth=8, name="semesterbild@high_resolution+realistic+extreme_quality depth 8 (text.obj)"),
+    # the reference's own feature values beside the two BASELINE configs above (SURVEY 8a notes / 8d):
+    # configs[2] with the mesh the reference's feature set would load (no high_quality_model / medium_resolution ->
+    # text_lowres.obj, 1 639 triangles, src/main.rs:31-35)
+    "c3lowres": dict(features=["high_resolution", "anti_aliasing", "soft_shadows"], model="text_lowres", scene="semesterbild",
+                     name="semesterbild@high_resolution+anti_aliasing+soft_shadows (text_lowres.obj)"),
+    # configs[3] at the depth `realistic + extreme_quality` means in the reference: 21 / 21 (raytracer_renderer.rs:55-73)
+    "c4d21": dict(features=["high_resolution", "realistic", "extreme_quality"], model="text", scene="semesterbild",
+                  depth=21, name="semesterbild@high_resolution+realistic+extreme_quality depth 21 (text.obj)"),
     # configs[4]: as c4 at 4K (the scene is aspect dependent, lib.rs:73-79)
     "c5": dict(features=["realistic", "extreme_quality"], model="text", scene="semesterbild", depth=8, size=(3840, 2160),
                name="semesterbild@3840x2160+realistic+extreme_quality depth 8 (text.obj)"),
 }
-DOMINANT_KERNEL = {"c1": "rt_primary_kernel", "c2": "rt_primary_kernel", "c3": "rt_primary_kernel",
-                   "c4": "rt_shade_kernel", "c5": "rt_shade_kernel"}
+DOMINANT_KERNEL = {"c1": "rt_primary_kernel", "c2": "rt_primary_kernel", "c3": "rt_primary_kernel", "c3lowres": "rt_primary_kernel",
+                   "c4": "rt_shade_kernel", "c4d21": "rt_shade_kernel", "c5": "rt_shade_kernel"}
 
 
 def build_workload(key):
@@ -106,11 +123,15 @@ def cpu_info():
 def cpu_baseline(cfg, flat, budget_s=18.0):
     """The reference's simd_render CPU path restated (kind "port": oracle/rt_simd_baseline.c -- 8-lane AVX2 packets
     of the 8/16/24 samples of a pixel, brute-force scan of every object per ray like the reference, rows of 48x48
-    tiles handed to a thread pool) timed on a bounded window of the same workload: one thread first (also sizes the
-    sample), then every core this process is granted."""
+    tiles handed to a thread pool) timed on a bounded sample of the same workload: one thread first (also sizes the
+    sample), then every core this process is granted.  The sample is a set of whole 48x48 tiles SPREAD OVER THE FRAME
+    (the tiles rank 0 of R would own under the lattice interleave of rt_tile_owner, R chosen for ~budget_s seconds), so
+    that it sees background, walls, text and spheres in the frame's own proportions.  Built on this machine with
+    -O3 -march=native when a C compiler is here, else the travelling x86-64-v3 build."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
+    build = oracle_lib.use_native_build()
     cores = oracle_lib.host_cores()
     cx, cy = cfg.width // 2, cfg.height // 2
     # one row segment of 8 pixels on one thread
@@ -120,24 +141,59 @@ def cpu_baseline(cfg, flat, budget_s=18.0):
     dt1 = max(s1["kernel_ms"] * 1e-3, 1e-3)
     rays1 = s1["rays_primary"] + s1["rays_reflection"] + s1["rays_refraction"]
     px_per_s_thread = 8 / dt1
-    # sample for ~budget_s on all cores: rows of 48-pixel tile segments (the work item of the pool)
-    n_px = float(np.clip(budget_s * px_per_s_thread * cores, 48 * cores, 48 * 48 * 64))
-    tiles_x = int(max(1, min(cfg.width // 48 - 1, np.ceil(np.sqrt(n_px / 2304.0)))))
-    w = 48 * tiles_x
-    h = int(max(1, min(cfg.height, np.ceil(n_px / w))))
-    win = (max(0, cx - w // 2), max(0, cy - h // 2), w, h)
-    _, _, st = oracle_lib.render(flat, cfg, window=win, n_threads=cores, aux=False, impl="simd")
+    # ~budget_s on all cores, in whole tiles (the probe sits where every pixel hits: the frame average is cheaper)
+    n_px = float(np.clip(budget_s * px_per_s_thread * cores * 1.2, 2304, cfg.width * cfg.height))
+    n_tiles_frame = -(-cfg.width // 48) * -(-cfg.height // 48)
+    share = int(max(1, round(n_tiles_frame * 2304 / n_px)))
+    _, _, st = oracle_lib.render(flat, cfg, n_ranks=share, rank=0, n_threads=cores, aux=False, impl="simd")
     dt = max(st["kernel_ms"] * 1e-3, 1e-3)
     rays = st["rays_primary"] + st["rays_reflection"] + st["rays_refraction"]
+    n_tiles = -(-n_tiles_frame // share)
     return {
         "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-        "sample": f"{win[2]}x{win[3]} px window at frame centre, {rays} rays + {st['rays_shadow']} shadow rays in {dt:.1f} s; "
-                  f"8-lane AVX2 packets, 48x48 tiles, brute-force scan of {flat.n_objects} objects per ray (restated "
-                  f"simd_render: the reference is Rust nightly and cannot be built offline)",
+        "sample": f"{n_tiles} of the frame's {n_tiles_frame} 48x48 tiles, spread over the frame (lattice interleave 1/{share}): "
+                  f"{rays} rays + {st['rays_shadow']} shadow rays in {dt:.1f} s; 8-lane AVX2 packets, rows of 48x48 tiles, brute-force "
+                  f"scan of {flat.n_objects} objects per ray (restated simd_render: the reference is Rust nightly and cannot "
+                  f"be built offline)",
+        "build": build,
         "mshadow_per_s": st["rays_shadow"] / dt / 1e6,
-        "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mray/s", "sample": f"8 px, {dt1:.2f} s"},
-        "parallel_efficiency": (rays / dt) / (rays1 / dt1) / cores,
+        "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mray/s", "sample": f"8 px at the frame centre, {dt1:.2f} s"},
         "cpu_model": cpu_info(), "cpus_visible": os.cpu_count(), "cpus_granted": cores,
+    }
+
+
+def boundary_costs(cfg, flat, lib, _abi, _lib, device):
+    """What a drop-in pays around the hot path, end to end: scene preparation (host BVH + 8 octant copies + threaded
+    copy + receiver-cell tables + upload), the first rt_render call (adds the sample-table uploads and, with soft
+    shadows, rt_flags_kernel) and a steady-state rt_render call (host buffer in, packed pixels out over PCIe), plus the
+    Python mirror's per-call flatten() + fingerprint() (RaytracerRenderer.render re-reads the scene like the reference's
+    render(&buffer, &scene)).  The reference's analogue is ONE call, src/main.rs:330-334."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import scenes as _scenes  # noqa: F401
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+
+    t = time.perf_counter()
+    ds = DeviceScene(flat, device=device)
+    scene_create_ms = (time.perf_counter() - t) * 1e3
+    p, keep = _abi.make_params(cfg)
+    host = np.zeros(cfg.width * cfg.height, np.uint32)
+    st = _abi.rt_stats()
+    calls, kern = [], []
+    for _ in range(4):
+        t = time.perf_counter()
+        _lib.check(lib.rt_render(ds.handle, C.byref(p), host.ctypes.data, None, C.byref(st)))
+        calls.append((time.perf_counter() - t) * 1e3)
+        kern.append(st.kernel_ms)
+    t = time.perf_counter()
+    fp = flat.fingerprint()
+    fingerprint_ms = (time.perf_counter() - t) * 1e3
+    ds.close()
+    del fp
+    return {
+        "scene_create_ms": scene_create_ms, "first_call_ms": calls[0], "steady_call_ms": float(np.median(calls[1:])),
+        "first_call_device_ms": kern[0], "steady_call_device_ms": float(np.median(kern[1:])),
+        "flags_and_tables_ms": kern[0] - float(np.median(kern[1:])), "fingerprint_ms": fingerprint_ms,
+        "note": "rt_render with a pageable host buffer: H2D of the fill + frame + D2H of the packed pixels; first call adds "
+                "table uploads and rt_flags_kernel (receiver flags, once per scene and light-cloud size)",
     }
 
 
@@ -148,6 +204,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary-costs", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="frames in flight (streams used alternately).  0 = 2 for frames without secondary rays (the head of a "
+                         "frame fills the CUs the drain of the one before leaves idle), 1 otherwise")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
@@ -178,35 +238,42 @@ def main():
 
     cfg, flat, wname = build_workload(args.workload)
     lib = _lib.load()
+    t_scene = time.perf_counter()
     ds = DeviceScene(flat, device=local_rank)
+    scene_create_ms = (time.perf_counter() - t_scene) * 1e3
     p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank)
     npix = cfg.width * cfg.height
-    fb = torch.zeros(npix, dtype=torch.int32, device=dev)
-    stream = torch.cuda.Stream(device=dev)
+    secondary = cfg.has("reflections") or cfg.has("refractions")
+    n_fly = args.in_flight or (1 if secondary else 2)
+    if args.backend == "gloo" and world > 1:
+        n_fly = 1  # (the host rehearsal synchronises every frame)
+    # one frame buffer and one stream per frame in flight (a displayed sequence is double buffered anyway)
+    fbs = [torch.zeros(npix, dtype=torch.int32, device=dev) for _ in range(n_fly)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_fly)]
     # N > 1: the library's own RCCL communicator (torch.distributed only carries its 128-byte id)
     rccl = RcclGather(world, rank, local_rank) if (world > 1 and args.backend == "nccl") else None
     host_gather = HostGather(cfg, world, rank) if (world > 1 and args.backend == "gloo") else None
     gather_ms_host = []
 
-    def frame(ev0=None, ev1=None):
-        with torch.cuda.stream(stream):
-            if ev0 is not None:
-                ev0.record(stream)
-            if rccl is not None:
-                rccl.render_gather(ds, p, fb.data_ptr(), stream.cuda_stream)
-            else:
-                _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None,
-                                                C.c_void_p(stream.cuda_stream)))
-            if ev1 is not None:
-                ev1.record(stream)
-            if host_gather is not None:  # rehearsal: the same staging layout through gloo on the host
-                stream.synchronize()
-                t = time.perf_counter()
-                host = fb.cpu().numpy().view(np.uint32)
-                host_gather.run(host)
-                if rank == 0:
-                    fb.copy_(torch.from_numpy(host.view(np.int32)))
-                gather_ms_host.append((time.perf_counter() - t) * 1e3)
+    def frame(i, ev0=None, ev1=None):
+        stream, fb = streams[i % n_fly], fbs[i % n_fly]
+        if ev0 is not None:
+            ev0.record(stream)
+        if rccl is not None:
+            rccl.render_gather(ds, p, fb.data_ptr(), stream.cuda_stream)
+        else:
+            _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None,
+                                            C.c_void_p(stream.cuda_stream)))
+        if ev1 is not None:
+            ev1.record(stream)
+        if host_gather is not None:  # rehearsal: the same staging layout through gloo on the host
+            stream.synchronize()
+            t = time.perf_counter()
+            host = fb.cpu().numpy().view(np.uint32)
+            host_gather.run(host)
+            if rank == 0:
+                fb.copy_(torch.from_numpy(host.view(np.int32)))
+            gather_ms_host.append((time.perf_counter() - t) * 1e3)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -214,17 +281,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 1 if world > 1 else 0)):  # N > 1: the first gather connects the peers (set-up, not a step)
-        frame()
+    for i in range(max(args.warmup, 1 if world > 1 else 0)):  # N > 1: the first gather connects the peers (set-up, not a step)
+        frame(i)
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    infos = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        frame(*evs[i])
+        frame(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    frame_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # device time of one step on the launch stream
+    # The dominant kernel's launch duration, for the roofline: frames one after the other on ONE stream, each bracketed by
+    # events on that stream (with two frames in flight a launch shares the GPU with its neighbour and its duration says
+    # nothing about the kernel).  Outside the timed region.
+    n_iso = max(1, min(args.steps, 20))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_iso)]
+    n_fly_timed, n_fly = n_fly, 1
+    for i in range(n_iso):
+        frame(0, *evs[i])
+    barrier()
+    n_fly = n_fly_timed
+    frame_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # device time of one step alone on its stream
+    infos = []
     if rccl is not None:
         infos.append(rccl.last())
 
@@ -284,12 +360,38 @@ def main():
                 "insts_salu": pmc.get("SQ_INSTS_SALU"), "insts_smem": pmc.get("SQ_INSTS_SMEM"),
                 "kernel_cycles": cycles, "source": pmc["_file"],
             }
+        # (3) flops, SURVEY 8(d): what the reference's brute-force scan would have spent on this frame's rays (every ray
+        # AND every shadow ray tests every object, raytracer.rs:48,180), and what the kernels actually executed (fp32
+        # vector instructions of the dominant kernel from the PMC summary x the lanes active in them; fma = 2 flop)
+        per_scan = FLOP_SPHERE * flat.n_spheres + FLOP_TRIANGLE * flat.n_triangles
+        brute = (rays + counts[3]) * per_scan
+        flops = {
+            "peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "unit": "Gflop/s",
+            "brute_force_equivalent": brute / sec_per_step / 1e9,
+            "brute_force_equivalent_frac_of_peak": brute / sec_per_step / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "flop_per_scan": per_scan,
+            "note": "brute-force equivalent = (rays + shadow rays, as the reference casts them) x (35 S + 85 T); above the "
+                    "vector peak means the BVH and the beam tests removed that work, not that the ALUs did it",
+            "bvh_actual": None, "bvh_actual_frac_of_peak": None,
+        }
+        if pmc and all(k in pmc for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32")):
+            lanes = 64.0
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
+                lanes = min(64.0, pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_ACTIVE_INST_VALU"])
+            wave_flop = 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_ADD_F32"] + \
+                pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            actual = wave_flop * lanes  # per frame of the dominant kernel
+            flops.update(bvh_actual=actual / (kernel_ms * 1e-3) / 1e9,
+                         bvh_actual_frac_of_peak=actual / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         bvh_actual_flop_per_frame=actual, active_lanes_per_valu_inst=lanes, source=pmc["_file"])
         out = {
-            "metric": "Mray/s (primary+secondary), semesterbild@high_resolution" if args.workload == "c3"
-                      else "Mray/s (primary+secondary)",
+            "metric": ("Mray/s (primary+secondary, rays counted as the reference casts them), semesterbild@high_resolution"
+                       if args.workload == "c3" else "Mray/s (primary+secondary, rays counted as the reference casts them)"),
             "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the rays the GPU actually traced (bit-identical repeats of the AA sample table are traced once)
+            "value_traced": counts[5] / sec_per_step / 1e6,
             "config": {
                 "workload": wname, "width": cfg.width, "height": cfg.height,
                 "rays_per_frame": rays, "rays_traced_per_frame": counts[5],
@@ -297,19 +399,24 @@ def main():
                 "mshadow_per_s": counts[3] / sec_per_step / 1e6,
                 "objects": flat.n_objects, "lights": int(flat.lights.shape[0]) * cfg.point_light_multiplicator,
                 "parallelism": f"tiles{cfg.render_stride}x{cfg.render_stride}/{world}gpu" + ("+rccl_gather" if world > 1 else ""),
+                "frames_in_flight": n_fly_timed,
                 "bvh": ds.bvh_info(), "build_id": build_id,
+                "notes": int(st.notes), "queue_bytes": int(st.queue_bytes),
+                "scene_create_ms": scene_create_ms,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": pmc["_file"] if (pmc and traffic is not None) else None,
                 "kernel": DOMINANT_KERNEL[args.workload], "kernel_ms": kernel_ms,
+                "kernel_ms_note": f"mean of {n_iso} launches alone on one stream, HIP events on that stream, after the timed region",
                 "algorithmic_bytes": own["rays_traced"] * ALG_BYTES_PER_RAY,
                 "note": "64 B per TRACED ray (SURVEY 8d ray-stream model); no ray touches HBM in this kernel, so this "
                         "fraction cannot rank it -- the applicable bound is `valu_issue` below",
                 "valu_issue": valu if valu is not None else
                 {"bound": "valu_issue", "frac": None,
                  "note": f"no profiles/*_{args.workload}_pmc.csv was collected on build {build_id} (tools/profile.sh)"},
+                "flops": flops,
             },
             "ranks": per_rank,
         }
@@ -320,12 +427,14 @@ def main():
             d2h = []
             for _ in range(4):
                 e0.record()
-                host.copy_(fb, non_blocking=True)
+                host.copy_(fbs[0], non_blocking=True)
                 e1.record()
                 torch.cuda.synchronize(dev)
                 d2h.append(e0.elapsed_time(e1))
             out["d2h_ms"] = float(np.median(d2h[1:]))
             out["config"]["mray_per_s_incl_d2h"] = rays / (sec_per_step + out["d2h_ms"] * 1e-3) / 1e6
+            if not args.no_boundary_costs:
+                out["boundary"] = boundary_costs(cfg, flat, lib, _abi, _lib, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, flat)
             out["cpu_baseline"]["gpu_over_cpu"] = mrays / out["cpu_baseline"]["value"]

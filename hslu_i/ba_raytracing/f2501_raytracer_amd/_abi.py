@@ -5,12 +5,15 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OOM, RT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 RT_FLAG_REFLECTIONS, RT_FLAG_REFRACTIONS, RT_FLAG_BACKFACE_CULLING, RT_FLAG_ANTI_ALIASING = 1, 2, 4, 8
 RT_TRAVERSAL_BVH, RT_TRAVERSAL_LINEAR = 0, 1
 RT_CAND_CAP_NONE = 0xFFFFFFFF
+RT_TILE_ORDER_DEFAULT, RT_TILE_ORDER_ROW_MAJOR, RT_TILE_ORDER_COST = 0, 1, 2
+(RT_NOTE_RECV_FLAGS_OFF_LIGHTS, RT_NOTE_RECV_FLAGS_OFF_CULLING, RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL, RT_NOTE_RECV_FLAGS_OFF_TUNING,
+ RT_NOTE_RECV_FLAGS_OFF_SCENE, RT_NOTE_HARD_PAIRS_OFF, RT_NOTE_FRAME_BATCHED) = 1, 2, 4, 8, 16, 32, 64
 
 _fp = C.POINTER(C.c_float)
 _up = C.POINTER(C.c_uint32)
@@ -24,7 +27,7 @@ class rt_bvh_tuning(C.Structure):
 class rt_tuning(C.Structure):
     _fields_ = [("shadow_candidate_cap", C.c_uint32), ("chunk_log2", C.c_uint32), ("no_aa_dedup", C.c_uint32),
                 ("no_counters", C.c_uint32), ("multi_force_rccl", C.c_uint32), ("no_receiver_flags", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("tile_order", C.c_uint32), ("sort_bits", C.c_uint32)]
 
 
 class rt_scene_desc(C.Structure):
@@ -69,6 +72,7 @@ class rt_stats(C.Structure):
         ("wave_nearest_nodes", C.c_uint64), ("wave_nearest_tris", C.c_uint64),
         ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
         ("wave_nearest_tris_exact", C.c_uint64), ("wave_shadow_tris_exact", C.c_uint64),
+        ("notes", C.c_uint32), ("reserved0", C.c_uint32), ("queue_bytes", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 EXPORTS = (
     "rt_device_count", "rt_scene_create", "rt_render", "rt_render_device", "rt_render_collect_stats",
     "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info", "rt_build_id", "rt_selftest_exact_math",
-    "rt_gather_layout", "rt_render_multi", "rt_multi_release", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy",
+    "rt_gather_layout", "rt_render_multi", "rt_render_multi_begin", "rt_render_multi_end", "rt_multi_release", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy",
     "rt_render_gather_device", "rt_comm_last_gather",
 )
 
@@ -58,6 +58,10 @@ def load():
     lib.rt_gather_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     lib.rt_render_multi.restype = C.c_int
     lib.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(rt_params), C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_render_multi_begin.restype = C.c_int
+    lib.rt_render_multi_begin.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(rt_params), C.c_void_p, C.POINTER(C.c_int)]
+    lib.rt_render_multi_end.restype = C.c_int
+    lib.rt_render_multi_end.argtypes = [C.c_int, C.POINTER(rt_stats)]
     lib.rt_multi_release.restype = None
     lib.rt_comm_unique_id.restype = C.c_int
     lib.rt_comm_unique_id.argtypes = [C.c_void_p]

@@ -6,6 +6,7 @@
 // only enqueues async work on the caller's stream).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -69,7 +70,11 @@ void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
-  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb,
+  for (hipEvent_t e : s->frame_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (s->cnt_ev) (void)hipEventDestroy(s->cnt_ev);
+  if (s->cnt_host) (void)hipHostFree(s->cnt_host);
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb, &s->costmap,
                     &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags})
     b->release();
   delete s;
@@ -370,7 +375,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     put(&s->dev.off_lights, l.data(), l.size() * 4);
   }
-  if ((rc = s->counters.ensure(RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
+  if ((rc = s->counters.ensure(2 * RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
 
   if (blob.size() >= (size_t)1 << 32) return bail(fail(RT_ERR_UNSUPPORTED, "scene data exceeds 4 GiB"));
   if ((rc = upload(s->blob, blob.data(), blob.size())) != RT_OK) return bail(rc);
@@ -421,6 +426,8 @@ int rt_validate_params(const rt_params* p) {
     return fail(RT_ERR_INVALID_ARG, "tuning.shadow_candidate_cap > 64");
   if (p->tuning.chunk_log2 && (p->tuning.chunk_log2 < 10u || p->tuning.chunk_log2 > 26u))
     return fail(RT_ERR_INVALID_ARG, "tuning.chunk_log2 outside 10..26");
+  if (p->tuning.sort_bits && (p->tuning.sort_bits < 12u || p->tuning.sort_bits > 24u))
+    return fail(RT_ERR_INVALID_ARG, "tuning.sort_bits outside 12..24");
   return RT_OK;
 }
 
@@ -430,6 +437,7 @@ extern "C" {
 static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, hipStream_t stream,
                    RtDevParams* P) {
   memset(P, 0, sizeof(*P));
+  s->notes = 0;
   P->width = p->width;
   P->height = p->height;
   memcpy(P->focus, p->focus, sizeof(P->focus));
@@ -448,8 +456,10 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     if (!s->tables_ev) HIP_TRY(hipEventCreateWithFlags(&s->tables_ev, hipEventDisableTiming));
     // (also covers the host staging vectors below: the previous asynchronous upload has read them by now)
     if (s->tables_pending) HIP_TRY(hipStreamSynchronize(s->tables_stream));
-    if (s->rendered && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    for (int b = 0; b < 2; b++)  // every frame still in flight (on whatever stream) reads the old tables
+      if (s->frame_pending[b]) HIP_TRY(hipEventSynchronize(s->frame_ev[b]));
     uploaded = true;
+    s->tables_version++;
     return RT_OK;
   };
   P->aa_unique = 1;
@@ -542,6 +552,12 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->cand_cap = cap == RT_CAND_CAP_NONE ? 0u : (cap ? cap : 64u);
     // receiver flags: cells no triangle / sphere can shadow for a light skip the candidate walk (rt_flags_kernel)
     P->recv_flags = nullptr;
+    // (why the flags are off, when they are: rt_stats.notes)
+    if (p->tuning.no_receiver_flags || P->cand_cap != 64u) s->notes |= RT_NOTE_RECV_FLAGS_OFF_TUNING;
+    if (!s->n_cells || !(P->cloud_delta > 0.0f)) s->notes |= RT_NOTE_RECV_FLAGS_OFF_SCENE;
+    if (s->dev.n_lights > 8u) s->notes |= RT_NOTE_RECV_FLAGS_OFF_LIGHTS;
+    if (p->traversal != RT_TRAVERSAL_BVH) s->notes |= RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL;
+    if (p->flags & RT_FLAG_BACKFACE_CULLING) s->notes |= RT_NOTE_RECV_FLAGS_OFF_CULLING;
     if (!p->tuning.no_receiver_flags && P->cand_cap == 64u && s->n_cells && s->dev.n_lights <= 8u && p->traversal == RT_TRAVERSAL_BVH &&
         !(p->flags & RT_FLAG_BACKFACE_CULLING) && P->cloud_delta > 0.0f) {
       const float key[8] = {P->beam_delta, p->eps_distance, P->cloud_centre[0], P->cloud_centre[1], P->cloud_centre[2], 1.f, 0.f, 0.f};
@@ -561,6 +577,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   }
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;
+  s->sort_bits_wanted = p->tuning.sort_bits;
   if (p->win_w) {
     P->win_x0 = p->win_x0, P->win_y0 = p->win_y0, P->win_w = p->win_w, P->win_h = p->win_h;
   } else {
@@ -578,8 +595,20 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->aux_hit_id = aux_dev->hit_id;
     P->aux_hit_t = aux_dev->hit_t;
   }
-  P->counters = p->tuning.no_counters ? nullptr : (unsigned long long*)s->counters.p;
-  HIP_TRY(hipMemsetAsync(s->counters.p, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
+  {
+    // this frame's counter block: wait for the frame that used it last (two frames may be in flight on two streams);
+    // a frame with secondary rays also owns the queues and the accumulator: it waits for both
+    const int blk = (int)(s->frame_no++ & 1u);
+    const bool secondary = (p->flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
+    for (int b = 0; b < 2; b++) {
+      if (!s->frame_ev[b]) HIP_TRY(hipEventCreateWithFlags(&s->frame_ev[b], hipEventDisableTiming));
+      if (s->frame_pending[b] && (b == blk || secondary)) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[b], 0));
+    }
+    s->cur_block = blk;
+    unsigned long long* blk_p = (unsigned long long*)s->counters.p + (size_t)blk * RT_COUNTER_REPLICAS * 16;
+    P->counters = p->tuning.no_counters ? nullptr : blk_p;
+    HIP_TRY(hipMemsetAsync(blk_p, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
+  }
 
   const bool aa_on = P->aa_rays > 0;
   if (aa_on && P->aa_rays > 256) return fail(RT_ERR_UNSUPPORTED, "aa_rays > 256");
@@ -588,11 +617,21 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->morton_lo[a] = s->aabb_lo[a] - 0.01f * ext;
     P->morton_scale[a] = ext > 0.f ? 1024.0f / (1.02f * ext) : 0.f;
   }
-  // multi-GPU: launch workgroups only for the super-tiles that hold pixels of this rank's tiles
+  // The super-tiles (16x16 pixels) this launch renders, in launch order.  Multi-GPU: only those that hold pixels of this
+  // rank's tiles.  RT_TILE_ORDER_COST: heaviest first, by the cost map measured on a calibration frame of this shape.
   P->sup_list = nullptr;
   P->n_sup = ((P->win_w + 15u) / 16u) * ((P->win_h + 15u) / 16u);
-  if (P->n_ranks > 1) {
-    const uint32_t key[7] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->tile_size, P->n_ranks, P->rank};
+  const uint32_t order = p->tuning.tile_order == RT_TILE_ORDER_COST ? RT_TILE_ORDER_COST : RT_TILE_ORDER_ROW_MAJOR;
+  s->cost_wanted = false;
+  if (order == RT_TILE_ORDER_COST) {
+    const uint32_t ck[10] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->width, P->height, P->flags, P->aa_rays, P->light_mult,
+                             p->max_depth_reflection | (p->max_depth_refraction << 8) | (p->traversal << 16)};
+    if (memcmp(ck, s->cost_key, sizeof(ck)) != 0) s->cost_valid = false, memcpy(s->cost_key, ck, sizeof(ck));
+    s->cost_wanted = !s->cost_valid;  // the caller runs the calibration frame (calibrate_costs)
+  }
+  if (P->n_ranks > 1 || (order == RT_TILE_ORDER_COST && s->cost_valid)) {
+    const uint32_t key[8] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->tile_size, P->n_ranks, P->rank,
+                             order == RT_TILE_ORDER_COST && s->cost_valid ? 2u : 1u};
     if (memcmp(key, s->sup_key, sizeof(key)) != 0 || s->sup_host.empty()) {
       if ((rc = begin_upload()) != RT_OK) return rc;
       s->sup_host.clear();
@@ -603,12 +642,14 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
           uint32_t x0 = P->win_x0 + sx * 16u, y0 = P->win_y0 + sy * 16u;
           uint32_t x1 = x0 + 15u < P->win_x0 + P->win_w - 1u ? x0 + 15u : P->win_x0 + P->win_w - 1u;
           uint32_t y1 = y0 + 15u < P->win_y0 + P->win_h - 1u ? y0 + 15u : P->win_y0 + P->win_h - 1u;
-          bool own = false;
+          bool own = P->n_ranks <= 1;
           for (uint32_t yy : {y0, y1})
             for (uint32_t xx : {x0, x1})
               own = own || rt_tile_owner(xx / P->tile_size, yy / P->tile_size, P->n_ranks) == P->rank;
           if (own) s->sup_host.push_back(sy * st_x + sx);
         }
+      if (key[7] == 2u && s->cost_host.size() == (size_t)st_x * st_y)
+        std::stable_sort(s->sup_host.begin(), s->sup_host.end(), [&](uint32_t a, uint32_t b) { return s->cost_host[a] > s->cost_host[b]; });
       memcpy(s->sup_key, key, sizeof(key));
       if ((rc = s->suplist.ensure(s->sup_host.size() * 4 + 4)) != RT_OK) return rc;
       HIP_TRY(hipMemcpyAsync(s->suplist.p, s->sup_host.data(), s->sup_host.size() * 4, hipMemcpyHostToDevice, stream));
@@ -629,120 +670,50 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
 }
 
 // ---- frame scheduler -------------------------------------------------------------------------------
-// Without secondary rays a frame is ONE launch of the primary kernel.  With reflections/refractions
-// every child ray becomes an independent work item in HBM ("ray streaming"): the primary kernel and
-// each secondary launch append their children to the next level's queue, and queues are drained
-// deepest level first, so level k+1 never holds more than the children of one chunk of level k
-// (<= 2 * RT_CHUNK = capacity).  Pixel sums use a fixed-point accumulator (order independent,
-// hence bit-reproducible), resolved to packed pixels by a last kernel.
-// Rays per secondary launch / per primary batch ("chunk").  Deep tree levels hold few rays, and a launch
-// costs at least the serial time of one wavefront (lights x N shadow traversals), so launches must be
-// BIG: with 2 Mi-ray chunks 60 % of config 4's frame went to launches of < 1 Mi rays running at
-// 20-700 ns/ray instead of 7 (config 4: 1797 ms; 64 Mi-ray chunks: 452 ms).  The chunk is the whole
-// frame's primary rays when that fits: a queue level costs 2 * chunk * 48 B, and all levels together are
-// kept under RT_QUEUE_BUDGET -- this is what 288 GB of HBM are for.  RT_CHUNK_LOG2 overrides.
-static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;
-// Rays per primary batch / secondary launch.  The whole frame's primary work items if the queues of all levels fit the
-// budget -- at most RT_QUEUE_BUDGET and at most 60 % of the HBM that is free now plus what the scene's queues already
-// hold (a shared or partitioned device renders with smaller chunks instead of failing); otherwise the frame is cut into
-// EQUAL batches (a small last batch would pay the full chain of per-level launch floors for few rays: config 5 spent
-// 20 % of its frame on the last 13 % of its pixels).  tuning.chunk_log2 overrides.  `shrink` halves the result (OOM retry).
-static uint32_t choose_chunk(uint64_t primary_items, size_t bytes_per_item, size_t queues_held, uint32_t forced, uint32_t shrink) {
-  if (forced) return 1u << forced;
-  size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-    const size_t avail = (size_t)((double)(free_b + queues_held) * 0.6);
-    if (avail < budget) budget = avail;
-  }
-  uint64_t max_chunk = budget / bytes_per_item;
-  max_chunk >>= shrink;
-  if (max_chunk > (1ull << 28)) max_chunk = 1ull << 28;  // 32-bit ray indices, 2 x chunk per queue
-  if (max_chunk < (1ull << 16)) max_chunk = 1ull << 16;
-  const uint64_t items = primary_items ? primary_items : 1u;
-  const uint64_t n_batches = (items + max_chunk - 1) / max_chunk;
-  uint64_t chunk = (items + n_batches - 1) / n_batches;
-  chunk = (chunk + 255u) / 256u * 256u;  // whole workgroups
-  if (chunk < (1u << 10)) chunk = 1u << 10;
-  return (uint32_t)chunk;
-}
-#define RT_CHUNK (s->chunk)
-#define RT_QUEUE_CAP (2u * s->chunk)
+// Without secondary rays a frame is ONE launch of the primary kernel.  With reflections / refractions every child ray
+// becomes an independent work item in HBM ("ray streaming"): the reference's recursion (single_raytrace,
+// raytracer_renderer.rs:147-264: a node spawns calculate_reflection :526-729 and calculate_refractions :279-524) is run
+// LEVEL BY LEVEL.  Level k reads one of two ray queues and appends its children to the other:
+//     primary -> [hard pairs] -> for k = 1 .. depth:  trace(k) -> sort(k) -> shade(k) -> [hard pairs]  -> resolve
+// Every launch takes its size from the device (the counter the launch before it wrote) and walks it with a grid-stride
+// loop, so the host never waits for a level: a steady-state frame is enqueued without one synchronisation.  What the
+// host contributes is a GUESS of each grid -- the counts of the previous frame of the same shape, read back
+// asynchronously -- and the queue sizes.  Queues are sized by need: the first frame of a shape runs with a generous
+// estimate and is verified (one synchronisation at its end: were children or pairs dropped?); if so the queues grow to
+// what the counters say was needed and the frame is rendered again.  A verified shape renders asynchronously from then
+// on (the scene is static, so its ray counts repeat exactly).  Pixel sums use a fixed-point accumulator (order
+// independent, hence bit-reproducible), resolved to packed pixels by a last kernel.
+static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;  // hard ceiling; the real limit is half of the free HBM
+#define RT_CNT_OVERFLOW 0u                       // dropped children
+#define RT_CNT_LEVEL(k) (k)                      // 1 .. levels + 1: rays appended to level k (dropped ones included)
+#define RT_CNT_HARD(levels) ((levels) + 2u)      // hard pairs waiting
+#define RT_CNT_HARD_STAT(levels) ((levels) + 3u) // [0] dropped pairs, [1] largest batch of pairs
+#define RT_CNT_HITS(levels, k) ((levels) + 5u + (k))  // rays of level k that hit something
+#define RT_CNT_TOTAL(levels) (2u * (levels) + 8u)
 
-// Reads the queue counters (one small copy + one synchronisation) and traces the "hard" pairs the launch before
-// deferred (rt_hard_kernel), so that the hard queue is empty again before the next producer runs.
-static int sync_counts(rt_scene* s, RtDevParams& P, uint32_t levels, hipStream_t stream, uint32_t* host) {
-  uint32_t* counts = (uint32_t*)s->qcount.p;
-  HIP_TRY(hipMemcpyAsync(host, counts, (size_t)(levels + 4) * 4, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  const uint32_t nh = host[levels + 2];
-  if (nh && P.hard_q) {
-    if (nh > P.hard_capacity) return fail(RT_ERR_HIP, "hard-pair queue overflowed (%u pairs)", nh);
-    P.hard_in_count = nh;
-    hipError_t e = (hipError_t)rt_launch_hard(s->dev, P, stream);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "hard-pair launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemsetAsync(counts + levels + 2, 0, 4, stream));
-  }
-  return RT_OK;
+static uint32_t grid_for(uint64_t items, uint32_t per_wg, uint32_t cap_wgs) {
+  uint64_t w = (items + items / 16u + per_wg - 1u) / per_wg + 8u;  // a little above the guess; the loop covers the rest
+  if (w > cap_wgs) w = cap_wgs;
+  return w ? (uint32_t)w : 1u;
 }
 
-static int drain_level(rt_scene* s, RtDevParams& P, uint32_t k, uint32_t levels, hipStream_t stream) {
-  uint32_t host[64 + 4];
-  uint32_t* counts = (uint32_t*)s->qcount.p;
-  int rc0 = sync_counts(s, P, levels, stream, host);
-  if (rc0 != RT_OK) return rc0;
-  const uint32_t n = host[k];
-  if (n == 0) return RT_OK;
-  if (n > RT_QUEUE_CAP) return fail(RT_ERR_HIP, "ray queue %u overflowed (%u rays)", k, n);
-  float4* qbase = (float4*)s->queues.p;
-  const size_t qstride = (size_t)RT_QUEUE_PLANES * RT_QUEUE_CAP;
-  for (uint32_t off = 0; off < n; off += RT_CHUNK) {
-    P.q_in = qbase + (size_t)(k - 1) * qstride;
-    P.q_in_first = off;
-    P.q_in_count = (n - off) < RT_CHUNK ? (n - off) : RT_CHUNK;
-    if (k < levels) {
-      P.q_out = qbase + (size_t)k * qstride;
-      P.q_out_count = counts + k + 1;
-    } else {
-      P.q_out = nullptr;  // rays of the last level have depth 1: no children possible
-      P.q_out_count = nullptr;
-    }
-    // trace -> sort by hit point -> shade
-    hipError_t e = (hipError_t)rt_launch_trace(s->dev, P, stream);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
-    {
-      uint32_t* w = (uint32_t*)s->trace_ws.p;
-      size_t tmp_bytes = s->sort_tmp.cap;
-      e = (hipError_t)rt_sort_pairs(w + 2 * (size_t)RT_CHUNK, w + 3 * (size_t)RT_CHUNK, w + 4 * (size_t)RT_CHUNK,
-                                    w + 5 * (size_t)RT_CHUNK, P.q_in_count, s->sort_tmp.p, &tmp_bytes, stream);
-      if (e != hipSuccess) return fail(RT_ERR_HIP, "radix sort failed: %s", hipGetErrorString(e));
-    }
-    e = (hipError_t)rt_launch_shade(s->dev, P, stream);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
-    if (k < levels) {
-      int rc = drain_level(s, P, k + 1, levels, stream);
-      if (rc != RT_OK) return rc;
-    } else if (P.hard_q) {
-      int rc = sync_counts(s, P, levels, stream, host);  // pairs deferred by the last level's shading
-      if (rc != RT_OK) return rc;
-    }
-  }
-  HIP_TRY(hipMemsetAsync(counts + k, 0, 4, stream));
-  return RT_OK;
-}
+static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking);
 
-static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2);
-
-// A frame that fails half-way (queue overflow, HIP / sort / launch error, out of memory) leaves partial sums in the
-// pixel accumulator and rays in the queues: mark the accumulator dirty so that the next frame clears it.
-static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2) {
-  const int rc = render_frame_impl(s, P, stream, forced_chunk_log2);
+// A frame that fails half-way (HIP / launch error, out of memory) leaves partial sums in the pixel accumulator: mark
+// the accumulator dirty so that the next frame clears it.
+static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking = false) {
+  const int rc = render_frame_impl(s, P, stream, forced_chunk_log2, blocking);
   if (rc != RT_OK) s->acc_pixels = 0;
+  // marks the end of this frame's use of its counter block (prepare() of a later frame waits for it)
+  if (hipEventRecord(s->frame_ev[s->cur_block], stream) == hipSuccess) s->frame_pending[s->cur_block] = true;
+  s->last_block = s->cur_block;
   return rc;
 }
 
-static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2) {
+static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking) {
   const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
   const uint32_t total_wgs = rt_primary_total_wgs(P);
+  s->queue_bytes = 0;
   if (!secondary) {
     P.acc = nullptr;
     P.q_out = nullptr;
@@ -755,63 +726,213 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
   if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
   const size_t npix = (size_t)P.width * P.height;
-  if (s->acc_pixels != npix) {
-    if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->acc.p, 0, npix * 4 * sizeof(long long), stream));
-    s->acc_pixels = npix;
-  }
-  // queues: one per tree level, 2 x chunk rays each; on out-of-memory retry with half the chunk
-  // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs; the queue is
-  // sized for the worst case of one launch (every ray x every light: 64 B each), so a push can never fail.
+  const uint64_t items = (uint64_t)total_wgs * 256u;  // primary work items (threads) of the frame
+  // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs
   const bool hard = P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
-  const size_t bytes_per_item = (size_t)levels * 2u * 48u + 24u + (hard ? (size_t)s->dev.n_lights * 64u : 0u);
-  for (uint32_t shrink = 0;; shrink++) {
-    s->chunk = choose_chunk((uint64_t)total_wgs * 256u, bytes_per_item, s->queues.cap + s->hard.cap, forced_chunk_log2, shrink);
-    rc = s->queues.ensure((size_t)levels * RT_QUEUE_PLANES * RT_QUEUE_CAP * sizeof(float4));
-    if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)6 * RT_CHUNK * 4);
-    if (rc == RT_OK && hard) rc = s->hard.ensure(((size_t)RT_CHUNK * s->dev.n_lights + 64u) * 4u * sizeof(float4));
-    if (rc == RT_OK) break;
-    if (rc != RT_ERR_OOM || forced_chunk_log2 || shrink >= 12) return rc;
+  if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
+  const uint32_t n_cnt = RT_CNT_TOTAL(levels);
+  if ((rc = s->qcount.ensure((size_t)n_cnt * 4)) != RT_OK) return rc;
+  if (!s->cnt_host) HIP_TRY(hipHostMalloc((void**)&s->cnt_host, 160 * 4, hipHostMallocDefault));
+  if (!s->cnt_ev) HIP_TRY(hipEventCreateWithFlags(&s->cnt_ev, hipEventDisableTiming));
+
+  // ---- the shape of this frame: what its ray counts depend on.  Same key as the last verified frame = same counts.
+  StreamKey key;
+  memset(&key, 0, sizeof(key));
+  key.width = P.width, key.height = P.height, key.flags = P.flags, key.aa_rays = P.aa_rays, key.aa_unique = P.aa_unique;
+  key.light_mult = P.light_mult, key.depth_refl = P.max_depth_reflection, key.depth_refr = P.max_depth_refraction;
+  key.win[0] = P.win_x0, key.win[1] = P.win_y0, key.win[2] = P.win_w, key.win[3] = P.win_h;
+  key.tile_size = P.tile_size, key.n_ranks = P.n_ranks, key.rank = P.rank, key.traversal = P.traversal, key.cand_cap = P.cand_cap;
+  key.cloud_seed = P.cloud_seed, key.n_cloud_sets = P.n_cloud_sets, key.forced = forced_chunk_log2;
+  key.tables = s->tables_version;
+  memcpy(key.f, P.focus, 12), key.f[3] = P.fw, key.f[4] = P.fh, key.f[5] = P.fd, key.f[6] = P.eps_distance, key.f[7] = P.air_ior;
+  key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup;
+  if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
+    s->stream_key = key;
+    s->stream_verified = false;
+    s->est_valid = false;
+    s->q_cap = s->hard_cap = s->batch_items = 0;
   }
-  P.hard_q = hard ? (float4*)s->hard.p : nullptr;
-  P.hard_capacity = hard ? RT_CHUNK * s->dev.n_lights : 0u;
-  if ((rc = s->qcount.ensure((size_t)(levels + 4) * 4)) != RT_OK) return rc;
-  HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t)(levels + 4) * 4, stream));
-  uint32_t* counts = (uint32_t*)s->qcount.p;  // [0] = overflow flag, [k] = rays waiting at level k
-  {
-    // per-chunk trace workspace: t, id, key, key', idx, idx'  (6 x RT_CHUNK dwords) + sort scratch
-    size_t tmp_bytes = 0;
-    hipError_t se = (hipError_t)rt_sort_pairs(nullptr, nullptr, nullptr, nullptr, RT_CHUNK, nullptr, &tmp_bytes, stream);
-    if (se != hipSuccess) return fail(RT_ERR_HIP, "radix sort size query failed: %s", hipGetErrorString(se));
-    if ((rc = s->sort_tmp.ensure(tmp_bytes + 256)) != RT_OK) return rc;
-    uint32_t* w = (uint32_t*)s->trace_ws.p;
-    P.tr_t = (float*)w;
-    P.tr_id = (int32_t*)(w + (size_t)RT_CHUNK);
-    P.tr_key = w + 2 * (size_t)RT_CHUNK;
-    P.tr_idx = w + 4 * (size_t)RT_CHUNK;
-    P.sh_idx = w + 5 * (size_t)RT_CHUNK;
+  // the counts of an earlier frame of this shape, if their read-back has landed
+  if (s->cnt_pending && hipEventQuery(s->cnt_ev) == hipSuccess) {
+    s->cnt_pending = false;
+    if (s->cnt_host_levels == levels && s->cnt_host_valid) memcpy(s->est, s->cnt_host, n_cnt * 4), s->est_valid = true;
   }
-  P.acc = (long long*)s->acc.p;
-  P.q_capacity = RT_QUEUE_CAP;
-  P.q_overflow = counts;
-  P.hard_count = counts + levels + 2;
-  const uint32_t batch_wgs = RT_CHUNK / 256u;
-  for (uint32_t w0 = 0; w0 < total_wgs; w0 += batch_wgs) {
-    uint32_t n = (total_wgs - w0) < batch_wgs ? (total_wgs - w0) : batch_wgs;
-    P.batch_first_wg = w0;
-    P.q_out = (float4*)s->queues.p;
-    P.q_out_count = counts + 1;
-    hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, n, stream);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    if ((rc = drain_level(s, P, 1, levels, stream)) != RT_OK) return rc;
+
+  for (int attempt = 0;; attempt++) {
+    // ---- sizes.  Unknown shape: every level fits the primary work items (children usually thin out; a scene where
+    // they multiply is caught by the verification below), pairs = 1/8 of that.  Budget: half of the free HBM.
+    if (!s->q_cap) {
+      if (forced_chunk_log2) {
+        s->batch_items = 1u << forced_chunk_log2;
+        s->q_cap = 2u * s->batch_items;
+      } else {
+        s->batch_items = (uint32_t)std::min<uint64_t>(items, 1ull << 28);
+        s->q_cap = s->batch_items;
+      }
+      if (s->q_cap < (1u << 16)) s->q_cap = 1u << 16;
+      s->hard_cap = hard ? std::max<uint32_t>(s->q_cap / 8u, 1u << 16) : 0u;
+    }
+    size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
+    const size_t held = s->queues.cap + s->hard.cap + s->trace_ws.cap;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
+    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)(q * (2u * 64u + 4u) + (h ? (h + 64u) * 64u : 0u)); };
+    while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
+      // does not fit: smaller primary batches, queues and pair buffer in proportion
+      s->q_cap = std::max<uint32_t>(s->q_cap / 2u, 1u << 16);
+      s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
+      s->batch_items = std::max<uint32_t>(s->batch_items / 2u, 1u << 10);
+      s->stream_verified = false;
+    }
+    s->batch_items = (s->batch_items + 255u) / 256u * 256u;
+    P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : RT_SORT_BITS_DEFAULT;
+    const uint32_t n_buckets = 1u << P.sort_bits;
+    rc = s->queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
+    if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)s->q_cap * 4 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+    if (rc == RT_OK && hard) rc = s->hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
+    if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
+      s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
+      s->batch_items = std::max<uint32_t>(s->batch_items / 2u, 1u << 10);
+      continue;
+    }
+    if (rc != RT_OK) return rc;
+    if (s->acc_pixels != npix) {
+      if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
+      HIP_TRY(hipMemsetAsync(s->acc.p, 0, npix * 4 * sizeof(long long), stream));
+      s->acc_pixels = npix;
+    }
+    uint32_t* ws = (uint32_t*)s->trace_ws.p;
+    P.sh_idx = ws;
+    P.sort_hist = ws + s->q_cap;
+    P.sort_offs = P.sort_hist + n_buckets;
+    P.sort_tile = P.sort_offs + n_buckets;
+    if (s->sort_hist_clean != (void*)P.sort_hist || s->sort_hist_buckets != n_buckets) {
+      // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
+      HIP_TRY(hipMemsetAsync(P.sort_hist, 0, (size_t)n_buckets * 4, stream));
+      s->sort_hist_clean = (void*)P.sort_hist;
+      s->sort_hist_buckets = n_buckets;
+    }
+    s->queue_bytes = s->queues.cap + s->trace_ws.cap + (hard ? s->hard.cap : 0);
+    const uint32_t n_batches = (uint32_t)((items + s->batch_items - 1) / s->batch_items);
+    if (n_batches > 1) s->notes |= RT_NOTE_FRAME_BATCHED;
+
+    uint32_t* counts = (uint32_t*)s->qcount.p;
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_cnt * 4, stream));
+    P.acc = (long long*)s->acc.p;
+    P.q_capacity = s->q_cap;
+    P.q_overflow = counts + RT_CNT_OVERFLOW;
+    P.hard_q = hard ? (float4*)s->hard.p : nullptr;
+    P.hard_capacity = s->hard_cap;
+    P.hard_count = counts + RT_CNT_HARD(levels);
+    P.hard_stat = counts + RT_CNT_HARD_STAT(levels);
+    float4* const q[2] = {(float4*)s->queues.p, (float4*)s->queues.p + (size_t)s->q_cap * RT_QUEUE_QUADS};
+    const uint32_t cap_wgs = (s->q_cap + 255u) / 256u;
+    const bool guess = s->est_valid && n_batches == 1;  // grids from the previous frame's counts (else: whole capacity)
+    const uint32_t ppw = 64u / (P.light_mult < 2u ? 2u : P.light_mult), pairs_per_wg = 4u * (ppw ? ppw : 1u);
+    const uint32_t hard_cap_wgs = hard ? (s->hard_cap + pairs_per_wg - 1u) / pairs_per_wg : 1u;
+    auto run_hard = [&]() -> int {
+      if (!hard) return RT_OK;
+      const uint32_t g = guess ? grid_for(s->est[RT_CNT_HARD_STAT(levels) + 1u], pairs_per_wg, hard_cap_wgs) : std::min(hard_cap_wgs, 16384u);
+      hipError_t e = (hipError_t)rt_launch_hard(s->dev, P, g, stream);
+      if (e != hipSuccess) return fail(RT_ERR_HIP, "hard-pair launch failed: %s", hipGetErrorString(e));
+      HIP_TRY(hipMemsetAsync(P.hard_count, 0, 4, stream));  // (stream ordered: behind the kernel that read it)
+      return RT_OK;
+    };
+    const uint32_t batch_wgs = s->batch_items / 256u;
+    for (uint32_t w0 = 0; w0 < total_wgs; w0 += batch_wgs) {
+      if (w0) HIP_TRY(hipMemsetAsync(counts + 1, 0, (size_t)(levels + 1) * 4, stream));  // the next batch's level counters
+      const uint32_t nw = std::min(total_wgs - w0, batch_wgs);
+      P.batch_first_wg = w0;
+      P.q_in = nullptr, P.q_in_count = nullptr;
+      P.q_out = q[0];
+      P.q_out_count = counts + RT_CNT_LEVEL(1);
+      hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, nw, stream);
+      if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      for (uint32_t k = 1; k <= levels; k++) {
+        if ((rc = run_hard()) != RT_OK) return rc;  // the pairs the launch before deferred
+        P.q_in = q[(k - 1u) & 1u];
+        P.q_in_count = counts + RT_CNT_LEVEL(k);
+        P.sort_hits = counts + RT_CNT_HITS(levels, k);
+        if (k < levels) {
+          P.q_out = q[k & 1u];
+          P.q_out_count = counts + RT_CNT_LEVEL(k + 1u);
+        } else {
+          P.q_out = nullptr;  // rays of the last level have depth 1: no children possible
+          P.q_out_count = nullptr;
+        }
+        const uint32_t g_rays = guess ? grid_for(s->est[RT_CNT_LEVEL(k)], 256u, cap_wgs) : cap_wgs;
+        const uint32_t g_hits = guess ? grid_for(s->est[RT_CNT_HITS(levels, k)], 256u, cap_wgs) : cap_wgs;
+        e = (hipError_t)rt_launch_trace(s->dev, P, g_rays, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
+        e = (hipError_t)rt_launch_sort(P, g_rays, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
+        e = (hipError_t)rt_launch_shade(s->dev, P, g_hits, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+      }
+      if ((rc = run_hard()) != RT_OK) return rc;  // pairs deferred by the last level's shading
+    }
+    hipError_t e = (hipError_t)rt_launch_resolve(P, stream);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+
+    // ---- the frame's counters come back asynchronously (grids of the next frame); an unverified shape waits for them
+    if (s->cnt_pending && (!s->stream_verified || blocking)) {  // (an older read-back still owns the pinned buffer)
+      HIP_TRY(hipEventSynchronize(s->cnt_ev));
+      s->cnt_pending = false;
+    }
+    if (!s->cnt_pending) {
+      HIP_TRY(hipMemcpyAsync(s->cnt_host, counts, (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(s->cnt_ev, stream));
+      s->cnt_pending = true;
+      s->cnt_host_levels = levels;
+      s->cnt_host_valid = n_batches == 1;
+    }
+    if (s->stream_verified && !blocking) return RT_OK;
+    HIP_TRY(hipEventSynchronize(s->cnt_ev));
+    s->cnt_pending = false;
+    const uint32_t* c = s->cnt_host;
+    const uint32_t dropped = c[RT_CNT_OVERFLOW], dropped_pairs = c[RT_CNT_HARD_STAT(levels)];
+    if (!dropped && !dropped_pairs) {
+      if (s->cnt_host_valid) memcpy(s->est, c, n_cnt * 4), s->est_valid = true;
+      s->stream_verified = true;
+      return RT_OK;
+    }
+    // children or pairs were dropped: the counters say what the frame needed; render it again with that
+    if (attempt >= 6) return fail(RT_ERR_HIP, "%u child rays / %u pair batches were dropped (queues could not be sized)", dropped, dropped_pairs);
+    uint32_t need = 0;
+    for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, c[RT_CNT_LEVEL(k)]);
+    const uint32_t need_pairs = c[RT_CNT_HARD_STAT(levels) + 1u];
+    if (n_batches == 1 && !forced_chunk_log2) {
+      if (need > s->q_cap) s->q_cap = (uint32_t)std::min<uint64_t>((uint64_t)need + need / 16u + 256u, 0xFFFFFF00ull);
+      if (need_pairs > s->hard_cap) s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)need_pairs + need_pairs / 8u + 256u, 0xFFFFFF00ull);
+    } else {
+      // (batched or forced: the counters are those of the last batch only -- grow geometrically)
+      if (dropped) s->q_cap = (uint32_t)std::min<uint64_t>((uint64_t)s->q_cap * 2u, 0xFFFFFF00ull);
+      if (dropped_pairs) s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)s->hard_cap * 4u, 0xFFFFFF00ull);
+    }
+    s->est_valid = false;
+    s->acc_pixels = 0;  // partial sums: clear the accumulator
   }
-  hipError_t e = (hipError_t)rt_launch_resolve(P, stream);
-  if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
-  uint32_t ovf = 0;
-  HIP_TRY(hipMemcpyAsync(&ovf, counts, 4, hipMemcpyDeviceToHost, stream));
+}
+
+// prepare() + the calibration frame of RT_TILE_ORDER_COST when this frame shape has no cost map yet: the frame is rendered
+// once in row-major order with every wavefront of the primary kernel adding its run time to its super-tile's entry (a
+// complete, valid frame into the caller's buffer), the map is read back (one synchronisation, once per scene and frame
+// shape -- like the receiver flags) and prepare() runs again, now sorting the list.
+static int prepare_ordered(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, hipStream_t stream, RtDevParams* P,
+                           const uint32_t* stage_slot, uint32_t stage_tiles_x) {
+  int rc = prepare(s, p, argb_dev, aux_dev, stream, P);
+  if (rc != RT_OK || !s->cost_wanted) return rc;
+  const size_t n_sup_all = (size_t)((P->win_w + 15u) / 16u) * ((P->win_h + 15u) / 16u);
+  if ((rc = s->costmap.ensure(n_sup_all * 4 + 4)) != RT_OK) return rc;
+  HIP_TRY(hipMemsetAsync(s->costmap.p, 0, n_sup_all * 4, stream));
+  P->cost_map = (uint32_t*)s->costmap.p;
+  P->stage_slot = stage_slot;
+  P->stage_tiles_x = stage_tiles_x;
+  if ((rc = render_frame(s, *P, stream, p->tuning.chunk_log2)) != RT_OK) return rc;
+  s->cost_host.assign(n_sup_all, 0u);
+  HIP_TRY(hipMemcpyAsync(s->cost_host.data(), s->costmap.p, n_sup_all * 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  if (ovf) return fail(RT_ERR_HIP, "%u child rays were dropped (queue overflow)", ovf);
-  return RT_OK;
+  s->cost_valid = true;
+  return prepare(s, p, argb_dev, aux_dev, stream, P);
 }
 
 int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt_aux* aux_dev, void* hip_stream) {
@@ -820,7 +941,7 @@ int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const 
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(s->device));
   RtDevParams P;
-  if ((rc = prepare(s, p, argb_dev, aux_dev, (hipStream_t)hip_stream, &P)) != RT_OK) return rc;
+  if ((rc = prepare_ordered(s, p, argb_dev, aux_dev, (hipStream_t)hip_stream, &P, nullptr, 0)) != RT_OK) return rc;
   return render_frame(s, P, (hipStream_t)hip_stream, p->tuning.chunk_log2);
 }
 
@@ -828,7 +949,7 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   if (!s || !st) return fail(RT_ERR_INVALID_ARG, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   unsigned long long all[RT_COUNTER_REPLICAS * 16];
-  HIP_TRY(hipMemcpy(all, s->counters.p, sizeof(all), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(all, (unsigned long long*)s->counters.p + (size_t)s->last_block * RT_COUNTER_REPLICAS * 16, sizeof(all), hipMemcpyDeviceToHost));
   unsigned long long c[16] = {0};
   for (unsigned r = 0; r < RT_COUNTER_REPLICAS; r++)
     for (unsigned i = 0; i < 16; i++) c[i] += all[r * 16 + i];
@@ -847,6 +968,8 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   st->wave_nearest_tris_exact = c[12];
   st->wave_shadow_tris_exact = c[13];
   st->rays_traced = c[14];
+  st->notes = s->notes;
+  st->queue_bytes = s->queue_bytes;
   return RT_OK;
 }
 
@@ -895,9 +1018,9 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
   HIP_TRY(hipEventCreate(&ev.e0));
   HIP_TRY(hipEventCreate(&ev.e1));
   RtDevParams P;
-  if ((rc = prepare(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P)) != RT_OK) return rc;
+  if ((rc = prepare_ordered(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P, nullptr, 0)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(ev.e0, nullptr));
-  if ((rc = render_frame(s, P, nullptr, p->tuning.chunk_log2)) != RT_OK) return rc;
+  if ((rc = render_frame(s, P, nullptr, p->tuning.chunk_log2, true)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(ev.e1, nullptr));
   HIP_TRY(hipEventSynchronize(ev.e1));
   float ms = 0.f;
@@ -930,7 +1053,7 @@ int rt_render_device_staged(rt_scene* s, const rt_params* p, uint32_t* out_dev, 
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(s->device));
   RtDevParams P;
-  if ((rc = prepare(s, p, out_dev, nullptr, stream, &P)) != RT_OK) return rc;
+  if ((rc = prepare_ordered(s, p, out_dev, nullptr, stream, &P, stage_slot, tiles_x)) != RT_OK) return rc;
   P.stage_slot = stage_slot;
   P.stage_tiles_x = tiles_x;
   return render_frame(s, P, stream, p->tuning.chunk_log2);

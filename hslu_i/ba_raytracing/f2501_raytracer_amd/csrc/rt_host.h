@@ -53,6 +53,14 @@ struct EventPair {  // destroyed on every return path
   }
 };
 
+// what the ray counts of a frame with secondary rays depend on (besides the scene): a frame with the key of the last
+// verified frame renders without a synchronisation
+struct StreamKey {
+  uint32_t width, height, flags, aa_rays, aa_unique, light_mult, depth_refl, depth_refr, win[4], tile_size, n_ranks, rank, traversal,
+      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup;
+  float f[8];
+};
+
 struct rt_scene {
   int device = 0;
   RtDevScene dev{};
@@ -61,9 +69,27 @@ struct rt_scene {
   // per-render workspaces
   DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp, hard;
   std::vector<uint32_t> sup_host;
-  uint32_t sup_key[7] = {0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank the list was built for
+  uint32_t sup_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank, order the list was built for
+  // RT_TILE_ORDER_COST: measured cost per super-tile (window-relative index) for cost_key = frame shape + what a ray costs
+  DevBuf costmap;
+  std::vector<uint32_t> cost_host;
+  uint32_t cost_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool cost_valid = false, cost_wanted = false;
   size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
-  uint32_t chunk = 1u << 16;  // rays per secondary launch / primary batch of the current frame
+  // ray streaming (frames with secondary rays): sizes and device-side counters, see render_frame_impl
+  uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // rays per queue, pairs, primary work items per batch
+  StreamKey stream_key{};
+  bool stream_verified = false;  // a frame of this key ran without dropping a ray or a pair
+  uint32_t est[160] = {0};       // the counters of the last complete frame of this key (grids of the next one)
+  bool est_valid = false;
+  uint32_t* cnt_host = nullptr;  // pinned: asynchronous read-back of the counters
+  hipEvent_t cnt_ev = nullptr;
+  bool cnt_pending = false, cnt_host_valid = false;
+  uint32_t cnt_host_levels = 0;
+  uint32_t sort_bits_wanted = 0;    // rt_tuning.sort_bits of the current frame (0 = default)
+  void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
+  uint32_t sort_hist_buckets = 0;
+  uint32_t tables_version = 0;      // bumped whenever a parameter table (AA samples, light clouds, flags, tile list) is uploaded
   float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
   std::vector<float> aa_host, cloud_host, cloud_scaled;
@@ -81,6 +107,17 @@ struct rt_scene {
   uint32_t n_cells = 0, n_tri_cells = 0;
   float flags_key[8] = {-1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // beam_delta, eps, cloud centre: what the flags were built for
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
+  // Frames in flight.  Consecutive frames may be enqueued on different streams so that the head of one overlaps the
+  // drain of the other (a launch cannot end before its longest wavefront does).  What a frame without secondary rays
+  // owns is its counter block: two blocks, used alternately, each guarded by the event recorded behind the frame that
+  // used it last.  Frames with secondary rays own the queues and the accumulator and wait for everything before them.
+  hipEvent_t frame_ev[2] = {nullptr, nullptr};
+  bool frame_pending[2] = {false, false};
+  uint32_t frame_no = 0;
+  int cur_block = 0, last_block = 0;
+  // which fast paths the last frame did NOT take (rt_stats.notes)
+  uint32_t notes = 0;
+  size_t queue_bytes = 0;  // ray queues + hard-pair queue + sort workspace of the last frame with secondary rays
 };
 
 

@@ -135,51 +135,63 @@ struct RtDevParams {
   float* aux_hit_t;
   unsigned long long* counters;  // [RT_COUNTER_REPLICAS][16]: primary, reflection, refraction, shadow, written, wave stats
   // ---- ray streaming (only when reflections / refractions are enabled) ---------------------------
-  // A queue is 3 float4 planes of q_capacity entries (SoA -> coalesced 16 B/lane accesses):
-  //   plane 0 {o.xyz, n_start}  plane 1 {d.xyz, bits(depth << 2 | kind)}  plane 2 {W.rgb, bits(pixel)}
+  // A queue holds 64-byte ray records, 4 float4 each (one HBM line per ray: the shade kernel fetches rays in hit-point
+  // order, and a gathered record costs one line, not one line per field):
+  //   {o.xyz, n_start}  {d.xyz, bits(depth, kind, multiplicity)}  {W.rgb, bits(pixel)}  {t, bits(hit id), bits(bucket), bits(rank)}
+  // the last quad is written by rt_trace_kernel.  Two queues are used alternately: level k reads one and appends its
+  // children to the other.  ALL sizes stay on the device: a kernel reads how many rays / pairs / hits it has to process
+  // from the counters the kernel before it wrote, and walks them with a grid-stride loop (the host only guesses the grid).
   float4* q_out;          // children of this launch are appended here (nullptr: no children wanted)
-  uint32_t* q_out_count;  // device counter of q_out
-  uint32_t* q_overflow;   // device counter of dropped children (must stay 0)
+  uint32_t* q_out_count;  // device counter of q_out (counts dropped children too: it can exceed q_capacity)
+  uint32_t* q_overflow;   // device counter of dropped children (must stay 0; checked by the host after the frame)
   uint32_t q_capacity;
-  const float4* q_in;     // secondary kernel: rays [q_in_first, q_in_first + q_in_count)
-  uint32_t q_in_first, q_in_count;
+  float4* q_in;           // secondary kernels: the rays of this level
+  const uint32_t* q_in_count;  // device: how many (clamped to q_capacity by the reader)
   long long* acc;         // [W*H][4] fixed-point RGB accumulator + primary-hit flag (nullptr: direct write)
   // "Hard" (hit point, light) pairs: soft-shadow sets of INCOHERENT wavefronts (their shared candidate list overflows)
   // are not traced where they are found; every lane's pair is appended here and rt_hard_kernel traces it with the N
   // samples of the pair spread over N lanes.  4 float4 planes of hard_capacity + 64 entries (the last 64: dump slots
   // of idle lanes): {p, bits(material row)} {n, bits(light)} {view d, bits(pixel)} {W * atten, bits(multiplicity)}.
   float4* hard_q;         // nullptr: no deferral (no accumulator to add to, or no soft shadows)
-  uint32_t* hard_count;
+  uint32_t* hard_count;   // device: pairs appended since rt_hard_kernel last ran (producers add, rt_hard_kernel reads)
+  uint32_t* hard_stat;    // device: [0] dropped pairs (must stay 0), [1] largest hard_count seen this frame
   uint32_t hard_capacity;
-  uint32_t hard_in_count;  // rt_hard_kernel: pairs to trace
+  // hit-point ordering of a level's rays: a counting sort on the top sort_bits bits of the Morton key of the hit point
+  // (misses are not sorted at all: they are not shaded).  rt_trace_kernel takes a ray's rank inside its bucket from the
+  // histogram (one atomic per wavefront and bucket), two small kernels turn the histogram into offsets (and clear it),
+  // rt_sort_place_kernel writes ray index -> sorted position.  Sizes never leave the device.
+  uint32_t* sort_hist;    // [1 << sort_bits]: zero between uses
+  uint32_t* sort_offs;    // [1 << sort_bits]: bucket -> first sorted position inside its tile of RT_SORT_TILE buckets
+  uint32_t* sort_tile;    // [(1 << sort_bits) / RT_SORT_TILE]: tile -> first sorted position
+  uint32_t* sort_hits;    // device scalar: rays of this level that hit something (= rays rt_shade_kernel shades)
+  uint32_t* sh_idx;       // [q_capacity] sorted position -> ray index
+  uint32_t sort_bits;
   uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
   // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;
   // nullptr = all super-tiles of the window
   const uint32_t* sup_list;
   uint32_t n_sup;         // number of super-tiles to render (listed, or all of the window)
+  // calibration frame of RT_TILE_ORDER_COST: every wavefront of the primary kernel adds its run time (shader clock / 64)
+  // to the entry of the super-tile (window-relative index) its first pixel lies in; nullptr = not measuring
+  uint32_t* cost_map;
   // Morton key of a secondary hit point: q = (p - morton_lo) * morton_scale in [0, 1024)^3 (scene AABB, host)
   float morton_lo[3], morton_scale[3];
-  // secondary rays: trace -> sort by hit point -> shade (per queue chunk, indices relative to q_in_first)
-  float* tr_t;            // [chunk] hit distance
-  int32_t* tr_id;         // [chunk] canonical hit id, -1 miss
-  uint32_t* tr_key;       // [chunk] Morton key of the hit point (0xFFFFFFFF miss)
-  uint32_t* tr_idx;       // [chunk] identity permutation written by the trace kernel
-  const uint32_t* sh_idx; // [chunk] ray indices sorted by key (shade kernel)
 };
 
-#define RT_QUEUE_PLANES 3u
+#define RT_QUEUE_QUADS 4u   // float4 per ray record
+#define RT_SORT_TILE 4096u  // buckets per workgroup of the offset scan
+#define RT_SORT_BITS_DEFAULT 22u
 #define RT_COUNTER_REPLICAS 64u
 
 // kernel launchers (rt_kernels.hip); return hipError_t as int
 uint32_t rt_primary_pixels_per_wg(const RtDevParams& p);
 uint32_t rt_primary_total_wgs(const RtDevParams& p);
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
-int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, void* stream);
-int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream);
-// rocPRIM radix sort of (key, value) pairs (rt_sort.hip); tmp == nullptr: only returns the temp size
-int rt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n,
-                  void* tmp, size_t* tmp_bytes, void* stream);
-int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream);
+// secondary kernels: n_wgs = the host's guess of the grid (every kernel walks its device-side count with a grid-stride loop)
+int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
+int rt_launch_sort(const RtDevParams& p, uint32_t n_wgs_place, void* stream);  // histogram -> offsets -> sh_idx (rt_sort.hip)
+int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
+int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
 int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream);
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);

@@ -1349,11 +1349,12 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
   if (on) {
     uint32_t i = base + rankl;
     if (i < P.q_capacity) {
-      P.q_out[0 * (size_t)P.q_capacity + i] = make_float4(o.x, o.y, o.z, n_start);
-      P.q_out[1 * (size_t)P.q_capacity + i] = make_float4(d.x, d.y, d.z, __int_as_float(pack_dkm(depth, kind, mult)));
-      P.q_out[2 * (size_t)P.q_capacity + i] = make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix));
+      float4* rec = P.q_out + (size_t)i * RT_QUEUE_QUADS;  // one 64-byte record per ray (quad 3: rt_trace_kernel)
+      rec[0] = make_float4(o.x, o.y, o.z, n_start);
+      rec[1] = make_float4(d.x, d.y, d.z, __int_as_float(pack_dkm(depth, kind, mult)));
+      rec[2] = make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix));
     } else {
-      atomicAdd(P.q_overflow, 1u);  // host sizes batches so this cannot happen; reported as an error
+      atomicAdd(P.q_overflow, 1u);  // the host sizes the queues from the frame before; a drop makes it render the frame again
     }
   }
 }
@@ -1364,10 +1365,12 @@ __device__ __forceinline__ void hard_push(const RtDevParams& P, lanemask m, V3 p
                                           uint32_t pix, V3 Wa, uint32_t mult) {
   const uint32_t cnt = (uint32_t)__popcll(m);
   uint32_t base = 0;
-  if ((threadIdx.x & 63u) == 0) base = atomicAdd(P.hard_count, cnt);
+  if ((threadIdx.x & 63u) == 0) {
+    base = atomicAdd(P.hard_count, cnt);
+    if (base + cnt > P.hard_capacity) atomicAdd(&P.hard_stat[0], 1u);  // (a drop makes the host render the frame again, larger)
+  }
   base = __builtin_amdgcn_readfirstlane(base);
   const uint32_t rankl = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-  // (the host sizes the queue for every pair of the launch: base + rank < capacity)
   const uint32_t i = (lane_of(m) && base + rankl < P.hard_capacity) ? base + rankl : P.hard_capacity + (threadIdx.x & 63u);
   const size_t stride = (size_t)P.hard_capacity + 64u;
   P.hard_q[0 * stride + i] = make_float4(p.x, p.y, p.z, __uint_as_float(mat_row));
@@ -1625,6 +1628,25 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       continue;
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
+#if RT_PROFILE == 4  // how full the wavefronts are in each class of (wavefront, light) set (what lane compaction could gain)
+    {
+      const uint32_t nl = (uint32_t)__popcll(use_m);
+      uint32_t needy = nl;
+      if (!CULL && P.recv_flags && N > 1) {
+        uint32_t tix = threadIdx.x;
+        RT_OPAQUE(tix);
+        const uint32_t rf = __float_as_uint(stash[10u * 256u + tix]) >> l;
+        needy = (uint32_t)__popcll(use_m & ~wave_ballot((rf & 1u) && ((rf >> 8) & 1u)));
+      }
+      if (nothing) {
+        W.prof[0] += 1, W.prof[1] += nl;
+      } else {
+        W.prof[2] += 1, W.prof[3] += nl, W.prof[4] += needy;
+        W.prof[5] += (cand.count == RT_CAND_OVERFLOW) ? 1 : 0;
+      }
+      W.prof[6] += (uint32_t)__popcll(hit_m);
+    }
+#endif
 #if RT_PROFILE == 3
     uint32_t set_occ = 0, set_tot = 0, set_filt = 0;
 #endif
@@ -1890,7 +1912,9 @@ __device__ __forceinline__ void acc_add_fixed(const RtDevParams& P, uint32_t pix
 // few adjacent pixels -- maximally coherent for the wave-cooperative traversal.  Sample colours meet in LDS and
 // are summed per pixel in the reference's lane/packet order (antialiased_raytrace, raytracer_renderer.rs:918-1016).
 // ------------------------------------------------------------------------------------------------
-template <bool CULL, bool STREAM>
+// COST: the calibration variant of RT_TILE_ORDER_COST (wavefront run times per super-tile); a kernel of its own so that
+// the shipped kernels carry none of it.
+template <bool CULL, bool STREAM, bool COST = false>
 __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
                                              float* lds_stash, unsigned long long* lds_cnt) {
   Wave wv;
@@ -1928,6 +1952,8 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   };
   const PixelMap pm = map_thread(threadIdx.x);
   const bool pix_on = pm.on;
+  // cost calibration (RT_TILE_ORDER_COST): the wavefront's start time waits in LDS, not in SGPRs
+  if (COST && P.cost_map && (threadIdx.x & 63u) == 0) lds_cnt[16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
   const uint32_t gx = pm.gx, gy = pm.gy, k = pm.k;
   const float x = (float)gx * P.fw;  // renderer/mod.rs:176-180
   const float y = (float)gy * P.fh;
@@ -2037,6 +2063,11 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       }
     }
   }
+  if (COST && P.cost_map && (threadIdx.x & 63u) == 0) {
+    const unsigned long long dt = __builtin_readcyclecounter() - lds_cnt[16 + (threadIdx.x >> 6)];
+    const uint32_t ppw = 256u / n_thr, g = (P.batch_first_wg + blockIdx.x) * ppw + threadIdx.x / n_thr, sup_slot = g >> 8;
+    if (sup_slot < P.n_sup) atomicAdd(&P.cost_map[P.sup_list ? P.sup_list[sup_slot] : sup_slot], (uint32_t)(dt >> 6));
+  }
   wave_flush(wv, P, (uint32_t)__popcll(wave_ballot(wrote)), lds_cnt);
 }
 
@@ -2053,7 +2084,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
   __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIX * 256];  // (no fixed-point sums without secondary rays)
-  __shared__ unsigned long long lds_cnt[16];
+  __shared__ unsigned long long lds_cnt[20];  // 15 counters (wave_flush), [16..19]: wave start times (cost calibration)
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     primary_body<true, false>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   else
@@ -2064,11 +2095,26 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_kernel(RtDevScen
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
   __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
-  __shared__ unsigned long long lds_cnt[16];
+  __shared__ unsigned long long lds_cnt[20];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     primary_body<true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   else
     primary_body<false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+}
+
+// calibration frames of RT_TILE_ORDER_COST (once per scene and frame shape): the same kernels + the per-super-tile timers
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_cost_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ float4 lds_rgbh[256];
+  __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ unsigned long long lds_cnt[20];
+  const bool cull = (P.flags & RT_FLAG_BACKFACE_CULLING) != 0;
+  if (P.acc) {
+    if (cull) primary_body<true, true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+    else primary_body<false, true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+  } else {
+    if (cull) primary_body<true, false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+    else primary_body<false, false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2084,9 +2130,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(Rt
 // (integer pixel accumulation).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ RayIn load_queued_ray(const RtDevParams& P, size_t j) {
-  float4 a = P.q_in[0 * (size_t)P.q_capacity + j];
-  float4 b = P.q_in[1 * (size_t)P.q_capacity + j];
-  float4 c = P.q_in[2 * (size_t)P.q_capacity + j];
+  const float4* rec = P.q_in + j * RT_QUEUE_QUADS;
+  float4 a = rec[0], b = rec[1], c = rec[2];
   RayIn r;
   r.o = mk(a.x, a.y, a.z);
   r.n_start = a.w;
@@ -2120,50 +2165,62 @@ template <bool CULL>
 __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevParams& P, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const bool have = i < P.q_in_count;
-  RayIn r = idle_ray();
-  if (have) r = load_queued_ray(P, (size_t)P.q_in_first + i);
-  V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
-  bool alive = have && !has_nan(d);
-  unsigned long long bal = wave_ballot(alive);
-  Hit h;
-  h.t = INFINITY;
-  h.id = -1;
-  if (bal) {
-    if (P.weighted) {
-      wv.cnt_kind[1] += wave_sum((alive && r.kind == KIND_REFL) ? r.mult : 0u);
-      wv.cnt_kind[2] += wave_sum((alive && r.kind == KIND_REFR) ? r.mult : 0u);
-    } else {
-      wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
-      wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
+  // how many rays this level holds is only known on the device (the kernel before appended them)
+  uint32_t n = uload(P.q_in_count);
+  n = n < P.q_capacity ? n : P.q_capacity;
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const bool have = i < n;
+    RayIn r = idle_ray();
+    if (have) r = load_queued_ray(P, (size_t)i);
+    V3 d = normalize(r.d_raw);  // Ray::new_with_mask, ray.rs:52-57
+    bool alive = have && !has_nan(d);
+    unsigned long long bal = wave_ballot(alive);
+    Hit h;
+    h.t = INFINITY;
+    h.id = -1;
+    if (bal) {
+      if (P.weighted) {
+        wv.cnt_kind[1] += wave_sum((alive && r.kind == KIND_REFL) ? r.mult : 0u);
+        wv.cnt_kind[2] += wave_sum((alive && r.kind == KIND_REFR) ? r.mult : 0u);
+      } else {
+        wv.cnt_kind[1] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFL));
+        wv.cnt_kind[2] += (uint32_t)__popcll(wave_ballot(alive && r.kind == KIND_REFR));
+      }
+      wv.cnt_traced += (uint32_t)__popcll(bal);
+      WSTAT(wv.cnt_pass += 1);
+      WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
+      h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
     }
-    wv.cnt_traced += (uint32_t)__popcll(bal);
-    WSTAT(wv.cnt_pass += 1);
-    WSTAT(wv.cnt_lanes += (uint32_t)__popcll(bal));
-    h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
-  }
-  if (have) {
     const bool hit = alive && h.id >= 0;
-    uint32_t key = 0xFFFFFFFFu;
+    uint32_t bucket = 0u, rank = 0u;
     if (hit) {
       V3 p = fma_s(d, h.t, r.o);
-      // 10 bits per axis over the scene's bounding box (host: prepare())
+      // 10 bits per axis over the scene's bounding box (host: prepare()); the top sort_bits bits order the shading
       uint32_t qx = (uint32_t)clampf((p.x - P.morton_lo[0]) * P.morton_scale[0], 0.0f, 1023.0f);
       uint32_t qy = (uint32_t)clampf((p.y - P.morton_lo[1]) * P.morton_scale[1], 0.0f, 1023.0f);
       uint32_t qz = (uint32_t)clampf((p.z - P.morton_lo[2]) * P.morton_scale[2], 0.0f, 1023.0f);
-      key = morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2);
+      bucket = (morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2)) >> (30u - P.sort_bits);
     }
-    P.tr_t[i] = h.t;
-    P.tr_id[i] = hit ? h.id : -1;
-    P.tr_key[i] = key;
-    P.tr_idx[i] = i;
+    // rank of the ray inside its bucket: one atomic per wavefront and distinct bucket (neighbouring rays mostly share one)
+    for (lanemask todo = wave_ballot(hit); todo;) {
+      const int fl = __ffsll((long long)todo) - 1;
+      const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bucket, fl);
+      const lanemask same = wave_ballot(bucket == b) & todo;
+      uint32_t first = 0;
+      if ((int)(threadIdx.x & 63u) == fl) first = atomicAdd(&P.sort_hist[b], (uint32_t)__popcll(same));
+      first = (uint32_t)__builtin_amdgcn_readlane((int)first, fl);
+      if (lane_of(same)) rank = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+      todo &= ~same;
+    }
+    if (have)
+      P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u] = make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(bucket), __uint_as_float(rank));
   }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
 __global__ __launch_bounds__(256, 4) void rt_trace_kernel(RtDevScene sc, RtDevParams P) {
-  __shared__ unsigned long long lds_cnt[16];
+  __shared__ unsigned long long lds_cnt[20];  // 15 counters (wave_flush), [16..19]: wave start times (cost calibration)
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     trace_body<true>(sc, P, lds_cnt);
   else
@@ -2175,30 +2232,33 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
                                            unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  bool have = i < P.q_in_count;
-  RayIn r = idle_ray();
-  Hit h;
-  h.t = INFINITY;
-  h.id = -1;
-  if (have) {
-    const uint32_t j = P.sh_idx[i];  // i-th ray in hit-point order
-    h.t = P.tr_t[j];
-    h.id = P.tr_id[j];
-    have = h.id >= 0;                // misses sort to the end: whole wavefronts fall through
-    if (have) r = load_queued_ray(P, (size_t)P.q_in_first + j);
-  }
-  RayOut out = process_ray<CULL, true, true>(sc, P, wv, have, r, lds_stash, h);
-  if (out.hit) {
-    const long long* fx = stash_fix(lds_stash) + threadIdx.x;
-    acc_add_fixed(P, out.pix, fx[0], fx[256], fx[512], out.mult);
+  const uint32_t n = uload(P.sort_hits);  // the rays of this level that hit something, in hit-point order (misses are not listed)
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const bool have = i < n;
+    RayIn r = idle_ray();
+    Hit h;
+    h.t = INFINITY;
+    h.id = -1;
+    if (have) {
+      const size_t j = P.sh_idx[i];  // i-th ray in hit-point order: one 64-byte record
+      r = load_queued_ray(P, j);
+      const float4 q3 = P.q_in[j * RT_QUEUE_QUADS + 3u];
+      h.t = q3.x;
+      h.id = __float_as_int(q3.y);
+    }
+    RayOut out = process_ray<CULL, true, true>(sc, P, wv, have, r, lds_stash, h);
+    if (out.hit) {
+      const long long* fx = stash_fix(lds_stash) + threadIdx.x;
+      acc_add_fixed(P, out.pix, fx[0], fx[256], fx[512], out.mult);
+    }
   }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
-  __shared__ unsigned long long lds_cnt[16];
+  __shared__ unsigned long long lds_cnt[20];  // 15 counters (wave_flush), [16..19]: wave start times (cost calibration)
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     shade_body<true>(sc, P, lds_stash, lds_cnt);
   else
@@ -2256,13 +2316,13 @@ __device__ __forceinline__ void shadow_tris_lane(const RtDevScene& sc, lanemask 
 }
 
 template <bool CULL>
-__device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParams& P) {
+__device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParams& P, uint32_t wave_index, uint32_t n_pairs) {
   const uint32_t N = P.light_mult;   // 2..64 (host)
   const uint32_t ppw = 64u / N;      // pairs per wavefront
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t pw = lane / N, j = lane - pw * N;
-  const uint32_t pair = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ppw + pw;
-  const bool have = pw < ppw && pair < P.hard_in_count;
+  const uint32_t pair = wave_index * ppw + pw;
+  const bool have = pw < ppw && pair < n_pairs;
   const lanemask grp = wave_ballot(have);
   if (!grp) return;
   const size_t stride = (size_t)P.hard_capacity + 64u;
@@ -2325,10 +2385,18 @@ __device__ __forceinline__ void hard_body(const RtDevScene& sc, const RtDevParam
 }
 
 __global__ __launch_bounds__(256) void rt_hard_kernel(RtDevScene sc, RtDevParams P) {
-  if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    hard_body<true>(sc, P);
-  else
-    hard_body<false>(sc, P);
+  // the pairs the launch before deferred: their number is only known on the device
+  const uint32_t n_raw = uload((const uint32_t*)P.hard_count);
+  const uint32_t n_pairs = n_raw < P.hard_capacity ? n_raw : P.hard_capacity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&P.hard_stat[1], n_raw);  // (sizes the queue of the next frame)
+  const uint32_t ppw = 64u / P.light_mult;
+  const uint32_t n_waves = (n_pairs + ppw - 1u) / ppw;
+  for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_waves; w += gridDim.x * 4u) {
+    if (P.flags & RT_FLAG_BACKFACE_CULLING)
+      hard_body<true>(sc, P, w, n_pairs);
+    else
+      hard_body<false>(sc, P, w, n_pairs);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2493,32 +2561,29 @@ uint32_t rt_primary_total_wgs(const RtDevParams& p) {
 
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;  // nothing owned inside the window
-  if (p.acc)
+  if (p.cost_map)
+    hipLaunchKernelGGL(rt_primary_cost_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else if (p.acc)
     hipLaunchKernelGGL(rt_primary_stream_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   else
     hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
-int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, void* stream) {
-  uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
-  if (n_wgs == 0) return 0;
+int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) n_wgs = 1;
   hipLaunchKernelGGL(rt_trace_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
-int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, void* stream) {
-  uint32_t n_wgs = (p.q_in_count + 255u) / 256u;
-  if (n_wgs == 0) return 0;
+int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) n_wgs = 1;
   hipLaunchKernelGGL(rt_shade_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
-int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, void* stream) {
-  const uint32_t ppw = 64u / (p.light_mult < 2u ? 2u : p.light_mult);
-  const uint32_t pairs_per_wg = 4u * (ppw ? ppw : 1u);
-  const uint32_t n_wgs = (p.hard_in_count + pairs_per_wg - 1u) / pairs_per_wg;
-  if (n_wgs == 0) return 0;
+int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) n_wgs = 1;
   hipLaunchKernelGGL(rt_hard_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }

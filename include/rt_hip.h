@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u
 
 /* ---- error codes -------------------------------------------------------------------------- */
 #define RT_OK 0
@@ -121,8 +121,19 @@ typedef struct rt_tuning {
    * when no triangle / sphere can touch a shadow ray that starts in the cell (computed once per scene and light-cloud
    * size by rt_flags_kernel); wavefronts whose hit points all lie in clear cells skip the candidate walk -- same image */
   uint32_t no_receiver_flags;
-  uint32_t reserved[2];
+  /* Launch order of the 16x16-pixel super-tiles of a frame (RT_TILE_ORDER_*).  The reference hands its tiles to a
+   * work-stealing pool in shuffled order (src/image_buffer.rs:48-97); a GPU launch runs its workgroups in list order, and
+   * cannot end before its longest wavefront does.  COST: the cost of every super-tile is measured once per scene and
+   * frame shape (one calibration frame, shader-clock sums per super-tile) and the list is launched heaviest first. */
+  uint32_t tile_order;
+  /* Secondary rays are shaded in the order of their hit points: a counting sort on the top `sort_bits` bits of the 30-bit
+   * Morton key of the hit point (12..24; 0 = default).  More bits = neighbouring rays in a wavefront lie closer together
+   * (their soft-shadow candidate walks are shared), at 8 bytes of device memory per bucket. */
+  uint32_t sort_bits;
 } rt_tuning;
+#define RT_TILE_ORDER_DEFAULT 0u
+#define RT_TILE_ORDER_ROW_MAJOR 1u
+#define RT_TILE_ORDER_COST 2u
 
 typedef struct rt_params {
   uint32_t abi_version; /* RT_ABI_VERSION */
@@ -211,7 +222,18 @@ typedef struct rt_stats {
   uint64_t wave_shadow_passes; /* wavefront-level shadow-ray traversals */
   uint64_t wave_nearest_tris_exact; /* triangle tests that passed the conservative pre-filter */
   uint64_t wave_shadow_tris_exact;
+  /* RT_NOTE_* bits: fast paths this frame did NOT take, and why (the image is the same either way) */
+  uint32_t notes;
+  uint32_t reserved0;
+  uint64_t queue_bytes; /* device memory the frame's ray queues, hard-pair queue and sort workspace hold (0 without secondary rays) */
 } rt_stats;
+#define RT_NOTE_RECV_FLAGS_OFF_LIGHTS 0x1u    /* receiver flags need n_lights <= 8 */
+#define RT_NOTE_RECV_FLAGS_OFF_CULLING 0x2u   /* ... and no backface culling */
+#define RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL 0x4u /* ... and RT_TRAVERSAL_BVH */
+#define RT_NOTE_RECV_FLAGS_OFF_TUNING 0x8u    /* switched off by rt_tuning (no_receiver_flags / shadow_candidate_cap) */
+#define RT_NOTE_RECV_FLAGS_OFF_SCENE 0x10u    /* no receiver cells (no triangles / degenerate scene) or no light cloud */
+#define RT_NOTE_HARD_PAIRS_OFF 0x20u          /* incoherent soft-shadow sets are traced inline (light_mult > 64, linear, cap) */
+#define RT_NOTE_FRAME_BATCHED 0x40u           /* the ray queues did not fit: the frame ran in several primary batches */
 
 typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */
 
@@ -274,9 +296,12 @@ int rt_render(rt_scene* scene, const rt_params* params, uint32_t* argb, const rt
  * is enqueued on `hip_stream` (a hipStream_t, NULL = default stream).  Without reflections /
  * refractions this is one asynchronous kernel launch; with them the call drives the ray-streaming
  * passes and returns when the last pass has been enqueued (it synchronises the stream in between to
- * read queue sizes).  stats (if not
- * NULL) is filled with ray counters only after the caller synchronises AND calls
- * rt_render_collect_stats. */
+ * read queue sizes).  Ray counters: after the caller has synchronised, rt_render_collect_stats (those of the frame
+ * enqueued last).
+ * Consecutive frames of one scene may be enqueued on DIFFERENT streams: the library orders what they share (two
+ * counter blocks used alternately; frames with secondary rays own the ray queues and wait for every earlier frame), so
+ * two frames without secondary rays overlap -- the head of one fills the compute units the drain of the other leaves
+ * idle. */
 int rt_render_device(rt_scene* scene, const rt_params* params, uint32_t* argb_dev,
                      const rt_aux* aux_dev, void* hip_stream);
 int rt_render_collect_stats(rt_scene* scene, rt_stats* stats);
@@ -331,7 +356,18 @@ int rt_gather_layout(uint32_t width, uint32_t height, uint32_t tile_size, uint32
  * n_gpu == 1 is rt_render without aux planes.  Scenes on distinct GPUs use RCCL; several scenes on ONE GPU (only
  * useful to rehearse the tile logic on a single-GPU machine) are gathered with device-to-device copies. */
 int rt_render_multi(rt_scene* const* per_gpu, int n_gpu, const rt_params* params, uint32_t* argb, rt_stats* stats);
-/* frees the communicators / staging buffers rt_render_multi caches between calls (optional) */
+/* The same frame in two halves, for a host that renders frame after frame (the reference's window loop calls render()
+ * once per displayed frame, src/main.rs:342-347): `begin` uploads the caller's fill, enqueues every GPU's render and
+ * the gather, and returns a ticket (frames with reflections / refractions block until their ray-queue levels are through,
+ * as rt_render_device does); `end` waits for that frame and copies it into the argb given to `begin` (which must stay
+ * valid until then).  TWO frames may be in flight: the head of frame k+1 fills the compute units that the drain of
+ * frame k leaves idle -- a rank's share of a frame is a sub-millisecond launch that cannot end before its longest
+ * wavefront does.  A third `begin` before an `end` is refused (RT_ERR_INVALID_ARG).  rt_render_multi = begin + end.
+ * stats->rays_* are those of the frame enqueued LAST on each GPU. */
+int rt_render_multi_begin(rt_scene* const* per_gpu, int n_gpu, const rt_params* params, uint32_t* argb, int* ticket);
+int rt_render_multi_end(int ticket, rt_stats* stats);
+/* frees the communicators / staging buffers rt_render_multi caches between calls.  The cache is deliberately NOT freed
+ * at process exit (the HIP / RCCL runtimes may be gone by then); call this to release it earlier. */
 void rt_multi_release(void);
 
 /* (b) one process per GPU (torch.distributed / MPI style launchers): rank 0 makes an id, the host ships its 128 bytes
@@ -345,6 +381,14 @@ void rt_comm_destroy(rt_comm* comm);
  * refractions the render part synchronises the stream between ray-queue levels, as rt_render_device does).  On rank 0
  * argb_dev (DEVICE, W*H, pre-filled by the caller) holds the complete frame once the stream has drained; on the
  * other ranks it is not touched and may be NULL.  params->n_ranks / rank are ignored (the communicator's are used). */
+/* The render runs on hip_stream, the gather on a stream the communicator owns (in call order, behind this rank's render);
+ * hip_stream then waits for the gather, so work enqueued on it afterwards sees the complete frame.  Staging and receive
+ * buffers are double buffered: frame k+1 may be enqueued on ANOTHER stream while frame k drains and travels (two frames
+ * in flight; give rank 0 a second argb_dev for it).
+ * Failure on one rank: a rank whose render fails still sends its (zeroed) tiles / posts its receives and returns the
+ * error afterwards, so its peers are not left waiting; a rank that cannot even set the frame up (invalid arguments,
+ * no memory for the staging buffers) aborts the communicator (ncclCommAbort) -- the peers' calls fail instead of hanging,
+ * and the communicator must be re-created. */
 int rt_render_gather_device(rt_scene* scene, rt_comm* comm, const rt_params* params, uint32_t* argb_dev, void* hip_stream);
 
 #define RT_TRANSPORT_NONE 0u  /* one rank: nothing to gather */

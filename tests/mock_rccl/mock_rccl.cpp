@@ -89,6 +89,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   delete c;
   return ncclSuccess;
 }
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+  fprintf(stderr, "mock RCCL: ncclCommAbort(rank %d)\n", c ? c->rank : -1);
+  delete c;
+  return ncclSuccess;
+}
 ncclResult_t ncclCommCount(const ncclComm_t c, int* n) {
   *n = c->n;
   return ncclSuccess;

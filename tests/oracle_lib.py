@@ -15,6 +15,8 @@ SO = os.path.join(ORACLE_DIR, "_build", "librt_oracle.so")
 from hslu_i.ba_raytracing.f2501_raytracer_amd import _abi  # noqa: E402
 
 _lib = None
+SO_NATIVE = os.path.join(ORACLE_DIR, "_build", "librt_oracle_native.so")
+_build_desc = "-O2 -march=x86-64-v3 (built where the repo was built; travels to the GPU box)"
 
 
 def build(force: bool = False) -> str:
@@ -25,11 +27,27 @@ def build(force: bool = False) -> str:
     return SO
 
 
+def use_native_build() -> str:
+    """bench.py's cpu_baseline: rebuild the oracle ON THIS MACHINE with -O3 -march=native and use that build
+    from now on, if a C compiler is here; otherwise keep the travelling x86-64-v3 build.  Returns a description.  Only
+    timing uses this; parity tests run the default build."""
+    global _lib, SO, _build_desc
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if os.path.exists(SO_NATIVE):
+            SO, _lib = SO_NATIVE, None
+            _build_desc = "-O3 -march=native, built on this machine"
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return _build_desc
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
-    build()
+    if SO != SO_NATIVE:
+        build()
     lib = C.CDLL(SO)
     lib.rt_cpu_render.restype = C.c_int
     lib.rt_cpu_render.argtypes = [C.POINTER(_abi.rt_scene_desc), C.POINTER(_abi.rt_params), C.c_void_p,

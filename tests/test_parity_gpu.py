@@ -829,6 +829,14 @@ def test_render_multi_rccl_call_sequence(tmp_path):
     assert "a receive has no matching send" not in out.stderr and "has no matching receive" not in out.stderr
 
 
+def _loaded_hip_runtime():
+    """The HIP runtime librt_hip.so itself is linked against: dlsym on the library's own handle searches its dependency
+    tree, so hipMalloc & co. resolve to THAT runtime whatever else the process has mapped (a torch import brings its own
+    copy along) and whatever its soname is."""
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    return _lib.load()
+
+
 def test_render_gather_device_single_rank_and_errors():
     """The process-per-GPU entry points with one rank (no RCCL traffic): rt_comm_create / rt_render_gather_device /
     rt_comm_last_gather, HBM-resident frame."""
@@ -844,7 +852,7 @@ def test_render_gather_device_single_rank_and_errors():
     p, keep = _abi.make_params(cfg, n_ranks=7, rank=3)  # ignored: the communicator's are used
     # a device frame buffer straight from the HIP runtime the library itself is linked against (importing torch after
     # librt_hip.so would pull in a second, mismatching runtime)
-    hip = C.CDLL("libamdhip64.so.7")
+    hip = _loaded_hip_runtime()
     nbytes = cfg.width * cfg.height * 4
     fb = C.c_void_p()
     assert hip.hipMalloc(C.byref(fb), C.c_size_t(nbytes)) == 0
@@ -933,3 +941,221 @@ def test_progressive_bands_match_the_oracle():
     ch = lambda v: np.stack([(v >> sh) & 0xFF for sh in (0, 8, 16, 24)]).astype(np.int32)
     assert np.array_equal(buf.buffer == fill, want == fill)  # the same pixels keep the fill
     assert np.abs(ch(buf.buffer) - ch(want)).max() <= 1
+
+
+def test_two_frames_in_flight_on_two_streams():
+    """Consecutive frames of one scene on two streams (rt_render_device): the library orders what they share (counter
+    blocks, tables), the frames overlap on the GPU, and every frame -- whole or one rank's share -- equals the frame
+    rendered alone; the counters are those of the frame enqueued last.  Also a frame with secondary rays between them
+    (it owns the ray queues and waits for everything before it)."""
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    lib = _lib.load()
+    hip = _loaded_hip_runtime()
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.test_scene(cfg).flatten()
+    ref, _, st_ref = gpu_render(cfg, flat, aux=False)
+    ref3, _, _ = gpu_render(cfg, flat, aux=False, n_ranks=3, rank=1)
+    cfg2 = RenderConfig.from_features(["realistic", "anti_aliasing"], depth_override=3)
+    ref_sec, _, st_sec = gpu_render(cfg2, flat, aux=False)
+    ds = DeviceScene(flat, 0)
+    nbytes = cfg.width * cfg.height * 4
+    streams, fbs = [], []
+    for _ in range(2):
+        sp, fp = C.c_void_p(), C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(sp), 1) == 0  # hipStreamNonBlocking
+        assert hip.hipMalloc(C.byref(fp), C.c_size_t(nbytes)) == 0
+        streams.append(sp), fbs.append(fp)
+    p, keep = _abi.make_params(cfg)
+    p3, keep3 = _abi.make_params(cfg, n_ranks=3, rank=1)
+    p2, keep2 = _abi.make_params(cfg2)
+
+    def fetch(i):
+        got = np.zeros(cfg.width * cfg.height, np.uint32)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fbs[i], C.c_size_t(nbytes), 2) == 0
+        return got
+
+    def clear():
+        for fb in fbs:
+            assert hip.hipMemset(fb, 0, C.c_size_t(nbytes)) == 0
+        assert hip.hipDeviceSynchronize() == 0
+
+    clear()
+    for k in range(10):  # ten frames, alternating streams, nothing synchronised in between
+        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), fbs[k % 2], None, streams[k % 2]))
+    assert hip.hipDeviceSynchronize() == 0
+    assert np.array_equal(fetch(0), ref) and np.array_equal(fetch(1), ref)
+    st = _abi.rt_stats()
+    _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
+    assert st.rays_primary == st_ref["rays_primary"] and st.rays_shadow == st_ref["rays_shadow"]
+    clear()
+    # a whole frame, one rank's share, a frame with secondary rays, a whole frame again: four shapes back to back
+    _lib.check(lib.rt_render_device(ds.handle, C.byref(p), fbs[0], None, streams[0]))
+    _lib.check(lib.rt_render_device(ds.handle, C.byref(p3), fbs[1], None, streams[1]))
+    assert hip.hipDeviceSynchronize() == 0
+    assert np.array_equal(fetch(0), ref) and np.array_equal(fetch(1), ref3)
+    clear()
+    _lib.check(lib.rt_render_device(ds.handle, C.byref(p), fbs[0], None, streams[0]))
+    _lib.check(lib.rt_render_device(ds.handle, C.byref(p2), fbs[1], None, streams[1]))
+    _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))  # (the call above drained its stream)
+    assert st.rays_reflection == st_sec["rays_reflection"] and st.rays_refraction == st_sec["rays_refraction"]
+    assert st.queue_bytes > 0
+    _lib.check(lib.rt_render_device(ds.handle, C.byref(p), fbs[0], None, streams[0]))
+    assert hip.hipDeviceSynchronize() == 0
+    assert np.array_equal(fetch(0), ref) and np.array_equal(fetch(1), ref_sec)
+    ds.close()
+    for sp, fp in zip(streams, fbs):
+        assert hip.hipStreamDestroy(sp) == 0 and hip.hipFree(fp) == 0
+
+
+def test_render_multi_begin_end_two_frames_in_flight():
+    """rt_render_multi_begin / _end: two frames of a 3-rank split (several scenes on one GPU: device-to-device gather) in
+    flight at once, double-buffered staging; both equal the single-GPU frame; a third begin is refused; tickets are
+    single use."""
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    lib = _lib.load()
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.test_scene(cfg).flatten()
+    fills = (0x00112233, 0x00445566)
+    refs = []
+    r = RaytracerRenderer(cfg, device=0)
+    for fill in fills:
+        b = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+        r.render(b, flat)
+        refs.append(b.buffer.copy())
+    n = 3
+    ds = [DeviceScene(flat, 0) for _ in range(n)]
+    arr = (C.c_void_p * n)(*[d.handle for d in ds])
+    p, keep = _abi.make_params(cfg)
+    for rep in range(3):  # (slots are reused: frames 3..6 run on the buffers of frames 1..2)
+        bufs = [np.full(cfg.width * cfg.height, f, np.uint32) for f in fills]
+        t = [C.c_int(-1), C.c_int(-1), C.c_int(-1)]
+        _lib.check(lib.rt_render_multi_begin(arr, n, C.byref(p), bufs[0].ctypes.data, C.byref(t[0])))
+        _lib.check(lib.rt_render_multi_begin(arr, n, C.byref(p), bufs[1].ctypes.data, C.byref(t[1])))
+        assert lib.rt_render_multi_begin(arr, n, C.byref(p), bufs[1].ctypes.data, C.byref(t[2])) == _abi.RT_ERR_INVALID_ARG
+        assert b"in flight" in lib.rt_last_error()
+        st = _abi.rt_stats()
+        _lib.check(lib.rt_render_multi_end(t[0].value, C.byref(st)))
+        assert st.kernel_ms > 0 and st.rays_primary == r.last_stats["rays_primary"]
+        assert lib.rt_render_multi_end(t[0].value, None) == _abi.RT_ERR_INVALID_ARG  # single use
+        _lib.check(lib.rt_render_multi_end(t[1].value, None))
+        assert np.array_equal(bufs[0], refs[0]) and np.array_equal(bufs[1], refs[1])
+    assert lib.rt_render_multi_end(12345678, None) == _abi.RT_ERR_INVALID_ARG
+    lib.rt_multi_release()
+    for d in ds:
+        d.close()
+
+
+def test_cost_ordered_launch_renders_the_same_frame():
+    """rt_tuning.tile_order = RT_TILE_ORDER_COST: a calibration frame measures every super-tile, later frames launch the
+    heaviest first.  Same frame (whole, one rank's share, with secondary rays), same counters."""
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    flat = scenes.test_scene(cfg).flatten()
+    a0, _, s0 = gpu_render(cfg, flat, aux=False)
+    for _ in range(2):  # the calibration frame, then a sorted one
+        a1, _, s1 = gpu_render(cfg, flat, aux=False, tile_order=_abi.RT_TILE_ORDER_COST)
+        assert np.array_equal(a0, a1) and s0["rays_shadow"] == s1["rays_shadow"] and s0["pixels_written"] == s1["pixels_written"]
+    r = RaytracerRenderer(cfg, device=0)
+    outs = []
+    for order in (_abi.RT_TILE_ORDER_ROW_MAJOR, _abi.RT_TILE_ORDER_COST, _abi.RT_TILE_ORDER_COST):
+        b = ImageBuffer.new(cfg.width, cfg.height)
+        r.render(b, flat, n_ranks=4, rank=2, window=(100, 60, 500, 400), tuning=dict(tile_order=order))
+        outs.append(b.buffer.copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and (outs[0] != 0).any()
+    cfg2 = RenderConfig.from_features(["realistic", "anti_aliasing"], depth_override=3)
+    b0, _, t0 = gpu_render(cfg2, flat, aux=False)
+    b1, _, t1 = gpu_render(cfg2, flat, aux=False, tile_order=_abi.RT_TILE_ORDER_COST)
+    b2, _, t2 = gpu_render(cfg2, flat, aux=False, tile_order=_abi.RT_TILE_ORDER_COST)
+    assert np.array_equal(b0, b1) and np.array_equal(b0, b2) and t0["rays_refraction"] == t2["rays_refraction"]
+
+
+def test_nine_lights_fast_path_off_is_reported_and_matches_the_oracle():
+    """Receiver flags hold 8 lights per cell; a scene with more renders without them -- same image (oracle windows) -- and
+    rt_stats.notes says so.  Also the other reasons the flags can be off."""
+    import dataclasses
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], width_override=320, height_override=256, n_cloud_sets=16)
+    flat = room_scene(3, cfg)
+    rng = np.random.default_rng(5)
+    lights = np.zeros((9, 7), np.float32)
+    lights[:, :3] = rng.uniform([0.1, 0.05, 0.05], [0.9, float(cfg.scene_height) * 0.6, float(cfg.scene_depth) * 0.5], (9, 3))
+    lights[:, 3:6] = rng.uniform(0.4, 1.0, (9, 3))
+    lights[:, 6] = rng.uniform(0.1, 0.3, 9)
+    flat9 = dataclasses.replace(flat, lights=lights)
+    _, _, s9 = gpu_render(cfg, flat9, aux=False)
+    assert s9["notes"] & _abi.RT_NOTE_RECV_FLAGS_OFF_LIGHTS and not s9["notes"] & _abi.RT_NOTE_RECV_FLAGS_OFF_TUNING
+    compare(cfg, flat9, (100, 90, 48, 32))
+    compare(cfg, flat9, (20, 180, 40, 24))
+    _, _, s8 = gpu_render(cfg, dataclasses.replace(flat, lights=lights[:8]), aux=False)
+    assert s8["notes"] & 0x1F == 0, s8["notes"]
+    _, _, st = gpu_render(cfg, flat9, aux=False, no_receiver_flags=1)
+    assert st["notes"] & _abi.RT_NOTE_RECV_FLAGS_OFF_TUNING
+    _, _, sl = gpu_render(cfg, flat, (100, 90, 16, 8), traversal=_abi.RT_TRAVERSAL_LINEAR, aux=False)
+    assert sl["notes"] & _abi.RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL
+    cfgc = RenderConfig.from_features(["anti_aliasing", "soft_shadows", "backface_culling"], width_override=320, height_override=256,
+                                      n_cloud_sets=16)
+    _, _, sc = gpu_render(cfgc, flat, (100, 90, 16, 8), aux=False)
+    assert sc["notes"] & _abi.RT_NOTE_RECV_FLAGS_OFF_CULLING
+
+
+def test_config3_lowres_mesh_windows_vs_oracle():
+    """configs[2] with the mesh the reference's own feature set loads (text_lowres.obj, src/main.rs:31-35), as
+    bench.py --workload c3lowres builds it: windows against the brute-force oracle."""
+    cfg, flat, _ = bench.build_workload("c3lowres")
+    assert 1600 <= flat.n_triangles <= 1700 and cfg.aa_total_rays == 16 and cfg.point_light_multiplicator == 10
+    for win in ((400, 380, 32, 24), (548, 418, 32, 24), (1120, 600, 32, 24), (330, 700, 32, 24)):
+        compare(cfg, flat, win)
+
+
+def test_config4_depth21_windows_vs_oracle():
+    """configs[3] at the recursion depth `realistic + extreme_quality` means in the reference (21 / 21,
+    raytracer_renderer.rs:55-73), as bench.py --workload c4d21 builds it: the glass sphere's rim, the text, and one pixel of
+    the pile of metallic glass spheres (ray trees of thousands of nodes) against the brute-force oracle."""
+    cfg, flat, _ = bench.build_workload("c4d21")
+    assert cfg.max_depth_reflection == 21 and cfg.max_depth_refraction == 21 and cfg.aa_total_rays == 24
+    for win in ((556, 418, 8, 6), (400, 380, 8, 6), (1250, 986, 1, 2)):  # (the last: ~1 250 rays per pixel)
+        compare(cfg, flat, win)
+
+
+def test_streaming_frames_are_enqueued_without_waiting_for_the_gpu():
+    """Frames with reflections / refractions: every ray-tree level takes its size from the device, so once a frame shape
+    is verified (its first frame: one synchronisation at the end, were any rays dropped?) rt_render_device /
+    rt_render_gather_device return while the GPU is still rendering -- the call is a burst of launches, no host round
+    trip per level.  Config 4 (8 levels): the call must return with the stream still busy and take a fraction of the
+    frame's time; the frame equals the blocking rt_render; queue memory is sized by need."""
+    import ctypes as C
+    import time
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.distributed import RcclGather
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    cfg, flat, _ = bench.build_workload("c4")
+    hip = _loaded_hip_runtime()
+    ds = DeviceScene(flat, 0)
+    g = RcclGather(1, 0, 0)
+    p, keep = _abi.make_params(cfg)
+    nbytes = cfg.width * cfg.height * 4
+    fb, stream = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(fb), C.c_size_t(nbytes)) == 0 and hip.hipMemset(fb, 0, C.c_size_t(nbytes)) == 0
+    assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0
+    g.render_gather(ds, p, fb.value, stream.value)  # first frame of the shape: verified
+    assert hip.hipStreamSynchronize(stream) == 0
+    calls, totals, busy = [], [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        g.render_gather(ds, p, fb.value, stream.value)
+        t1 = time.perf_counter()
+        busy.append(hip.hipStreamQuery(stream))
+        assert hip.hipStreamSynchronize(stream) == 0
+        calls.append(t1 - t0), totals.append(time.perf_counter() - t0)
+    print(f"config 4: call returns after {1e3 * min(calls):.2f} ms, frame done after {1e3 * min(totals):.2f} ms")
+    assert all(b == 600 for b in busy), busy  # hipErrorNotReady: the stream had not drained when the call returned
+    assert min(calls) < 0.25 * min(totals)
+    got = np.zeros(cfg.width * cfg.height, np.uint32)
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fb, C.c_size_t(nbytes), 2) == 0
+    ref, _, st = gpu_render(cfg, flat, aux=False)
+    assert np.array_equal(got, ref)
+    assert 0 < st["queue_bytes"] <= 4 << 30, st["queue_bytes"]
+    g.close()
+    ds.close()
+    assert hip.hipStreamDestroy(stream) == 0 and hip.hipFree(fb) == 0

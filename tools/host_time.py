@@ -1,25 +1,77 @@
-import ctypes as C, os, sys, time
-sys.path.insert(0, '/root/repo')
-import numpy as np, torch
+#!/usr/bin/env python3
+"""One-GPU rehearsal of the tile-parallel split: GPU time per frame of ONE rank's share of a workload (n_ranks, rank:
+the tiles rt_tile_owner gives it), frames enqueued back to back through rt_render_device --
+
+  * on one stream (a launch cannot end before its longest wavefront does: every frame pays its own drain), and
+  * on two streams used alternately (two frames in flight: the head of frame k+1 fills the CUs frame k's drain leaves idle),
+
+in row-major and in cost order (rt_tuning.tile_order).  The per-rank figure bounds what an N-GPU run can reach before
+the gather: speed-up <= whole-frame ms / slowest rank's ms.
+
+Usage: host_time.py [workload] [--frames K] [--ranks 1,2,4,8]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
 import bench
 from hslu_i.ba_raytracing.f2501_raytracer_amd import _abi, _lib
 from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
-lib = _lib.load(); dev = torch.device('cuda', 0)
-cfg, flat, _ = bench.build_workload('c3')
+
+ap = argparse.ArgumentParser()
+ap.add_argument("workload", nargs="?", default="c3")
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--ranks", default="1,2,4,8")
+ap.add_argument("--orders", default="1,2")
+args = ap.parse_args()
+
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+cfg, flat, _ = bench.build_workload(args.workload)
 ds = DeviceScene(flat, 0)
-fb = torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev)
-for n_ranks, rank in ((1, 0), (8, 3), (8, 0), (4, 1), (2, 1)):
-    p, keep = _abi.make_params(cfg, n_ranks=n_ranks, rank=rank)
-    for _ in range(3):
-        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None, None))
-    torch.cuda.synchronize()
-    K = 50
-    t0 = time.perf_counter(); host = 0.0
-    for _ in range(K):
-        h0 = time.perf_counter()
-        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None, None))
-        host += time.perf_counter() - h0
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print(f"ranks {n_ranks} rank {rank}: pipelined {1e3*(t2-t0)/K:.3f} ms/frame, host enqueue {1e3*host/K:.3f} ms/frame")
+fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(2)]
+streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+K = args.frames
+ref = None
+whole = {}
+for n_ranks in (int(v) for v in args.ranks.split(",")):
+    for order in (int(v) for v in args.orders.split(",")):
+        rows = []
+        for rank in range(n_ranks):
+            p, keep = _abi.make_params(cfg, n_ranks=n_ranks, rank=rank, tuning=dict(tile_order=order))
+            res = []
+            for n_streams in (1, 2):
+                for i in range(4):  # warm-up (the first frame of a cost-ordered shape is the calibration frame)
+                    _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fbs[i % n_streams].data_ptr()), None,
+                                                    C.c_void_p(streams[i % n_streams].cuda_stream)))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fbs[i % n_streams].data_ptr()), None,
+                                                    C.c_void_p(streams[i % n_streams].cuda_stream)))
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                res.append((1e3 * (t2 - t0) / K, 1e3 * (t1 - t0) / K))
+            if n_ranks == 1:
+                img = fbs[0].cpu().numpy().view(np.uint32)
+                if ref is None:
+                    ref = img.copy()
+                assert np.array_equal(img, ref) and np.array_equal(fbs[1].cpu().numpy().view(np.uint32), ref), "image changed"
+            rows.append((rank, res))
+        tag = {1: "row-major", 2: "cost order"}[order]
+        for rank, res in rows:
+            print(f"ranks {n_ranks} rank {rank} {tag:10s}: 1 stream {res[0][0]:.3f} ms/frame, 2 streams {res[1][0]:.3f} ms/frame "
+                  f"(host enqueue {res[1][1]:.3f})")
+        slow1, slow2 = max(r[1][0][0] for r in rows), max(r[1][1][0] for r in rows)
+        if n_ranks == 1:
+            whole[order] = (slow1, slow2)
+        w = whole.get(order, whole.get(1, (slow1, slow2)))
+        print(f"== {n_ranks} ranks, {tag}: slowest rank {slow1:.3f} ms (1 stream) -> {w[0] / slow1:.2f}x, "
+              f"{slow2:.3f} ms (2 streams) -> {w[1] / slow2:.2f}x of the whole frame's {w[0]:.3f} / {w[1]:.3f} ms")
+ds.close()

@@ -72,7 +72,16 @@ for spec in args or ["c3"]:
     sp = max(1, st.wave_shadow_passes)
     print(f"{'':28s} per wave-pass: nearest nodes {st.wave_nearest_nodes/max(1,st.wave_ray_passes):.1f} tris {st.wave_nearest_tris/max(1,st.wave_ray_passes):.1f} | "
           f"shadow passes {st.wave_shadow_passes} nodes {st.wave_shadow_nodes/sp:.1f} tris {st.wave_shadow_tris/sp:.1f} exact {st.wave_shadow_tris_exact/sp:.2f}")
-    if os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
+    if os.environ.get("RT_HIP_LIB", "").endswith("_prof4.so"):
+        # make PROFILE=4 build: lane occupancy per class of (wavefront, light) set.  Counter order (wave_flush, RT_PROFILE):
+        # wave_ray_lanes = prof[6], nearest_nodes = prof[0], nearest_tris = prof[1], shadow_nodes = prof[2], shadow_tris = prof[3],
+        # nearest_tris_exact = prof[4], shadow_tris_exact = prof[5]
+        n_no, l_no, n_tr, l_tr = st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris
+        needy, n_ov, hits = st.wave_nearest_tris_exact, st.wave_shadow_tris_exact, st.wave_ray_lanes
+        print(f"{'':28s} sets with nothing to test: {n_no} ({l_no/max(1,n_no):.1f} lanes each) | sets traced: {n_tr} "
+              f"({l_tr/max(1,n_tr):.1f} lanes each, {needy/max(1,n_tr):.1f} of them in cells that are not clear; {n_ov} overflowed) | "
+              f"lane-lights in traced sets {100.0*l_tr/max(1,l_tr+l_no):.1f} %, needy {100.0*needy/max(1,l_tr+l_no):.1f} %")
+    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
         # make PROFILE=3 build: outcome of the candidate sets that had something to test
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
              st.wave_shadow_tris_exact]

@@ -21,7 +21,8 @@ build_id = open(os.path.join(src, "build_id.txt")).read().split()[0]
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join("profiles", f"{tag}_{wl}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
-n_frames = 4  # tools/profile.sh: --steps 3 --warmup 1
+nf = os.path.join(src, "n_frames.txt")
+n_frames = int(open(nf).read().split()[0]) if os.path.exists(nf) else 4  # frames per profiled run (tools/profile.sh)
 kern = [r for r in rows if kname in r["Name"]][0]
 calls = int(kern["Calls"])
 per_frame = calls / n_frames
