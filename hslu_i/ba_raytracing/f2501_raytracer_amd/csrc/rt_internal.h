@@ -137,7 +137,7 @@ struct RtDevParams {
   // ---- ray streaming (only when reflections / refractions are enabled) ---------------------------
   // A queue holds 64-byte ray records, 4 float4 each (one HBM line per ray: the shade kernel fetches rays in hit-point
   // order, and a gathered record costs one line, not one line per field):
-  //   {o.xyz, n_start}  {d.xyz, bits(depth, kind, multiplicity)}  {W.rgb, bits(pixel)}  {t, bits(hit id), bits(bucket), bits(rank)}
+  //   {o.xyz, n_start}  {d.xyz, bits(depth, kind, multiplicity)}  {W.rgb, bits(pixel)}  {t, bits(hit id), bits(Morton key of the hit point), bits(rank in its bucket)}
   // the last quad is written by rt_trace_kernel.  Two queues are used alternately: level k reads one and appends its
   // children to the other.  ALL sizes stay on the device: a kernel reads how many rays / pairs / hits it has to process
   // from the counters the kernel before it wrote, and walks them with a grid-stride loop (the host only guesses the grid).

@@ -1659,7 +1659,11 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     const V3 mmc_lc = mcolor * mc_lc;  // (the reference multiplies the surface colour in twice: contribution colour x surface colour)
     // this light's share of `direct` and `specular`, summed over its samples in sample order from zero (the same chain
     // rt_hard_kernel runs for a deferred pair)
-    V3 dl = mk(0.0f, 0.0f, 0.0f), ds = mk(0.0f, 0.0f, 0.0f);
+    // (without secondary rays nothing needs the per-light split: the chain simply runs on through all lights, in the
+    // running sums themselves -- six registers less in the sample loops of the kernel that has no hard route)
+    V3 dl_own = mk(0.0f, 0.0f, 0.0f), ds_own = mk(0.0f, 0.0f, 0.0f);
+    V3& dl = STREAM ? dl_own : light_color;
+    V3& ds = STREAM ? ds_own : spec_color;
     auto add_light = [&](auto filtered_tag, V3 ltp, const Shadow& S, lanemask reach_m) {
       constexpr bool FILTERED = decltype(filtered_tag)::value;
       const unsigned long long t_l = PROF_T();
@@ -1748,9 +1752,6 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       fx[0] += __float2ll_rn(c.x * RT_ACC_SCALE);
       fx[256] += __float2ll_rn(c.y * RT_ACC_SCALE);
       fx[512] += __float2ll_rn(c.z * RT_ACC_SCALE);
-    } else {
-      light_color = light_color + dl;
-      spec_color = spec_color + ds;
     }
 #if RT_PROFILE == 3  // outcome of the (wavefront, light) sets that had something to test
     if (!nothing && set_tot) {
@@ -2193,14 +2194,15 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
       h = nearest_hit<CULL>(sc, P, wv.ctx, alive, r.o, d);
     }
     const bool hit = alive && h.id >= 0;
-    uint32_t bucket = 0u, rank = 0u;
+    uint32_t key = 0u, bucket = 0u, rank = 0u;
     if (hit) {
       V3 p = fma_s(d, h.t, r.o);
       // 10 bits per axis over the scene's bounding box (host: prepare()); the top sort_bits bits order the shading
       uint32_t qx = (uint32_t)clampf((p.x - P.morton_lo[0]) * P.morton_scale[0], 0.0f, 1023.0f);
       uint32_t qy = (uint32_t)clampf((p.y - P.morton_lo[1]) * P.morton_scale[1], 0.0f, 1023.0f);
       uint32_t qz = (uint32_t)clampf((p.z - P.morton_lo[2]) * P.morton_scale[2], 0.0f, 1023.0f);
-      bucket = (morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2)) >> (30u - P.sort_bits);
+      key = morton_expand10(qx) | (morton_expand10(qy) << 1) | (morton_expand10(qz) << 2);
+      bucket = key >> (30u - P.sort_bits);
     }
     // rank of the ray inside its bucket: one atomic per wavefront and distinct bucket (neighbouring rays mostly share one)
     for (lanemask todo = wave_ballot(hit); todo;) {
@@ -2214,7 +2216,7 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
       todo &= ~same;
     }
     if (have)
-      P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u] = make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(bucket), __uint_as_float(rank));
+      P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u] = make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(key), __uint_as_float(rank));
   }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
@@ -2235,13 +2237,14 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
   const uint32_t n = uload(P.sort_hits);  // the rays of this level that hit something, in hit-point order (misses are not listed)
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + threadIdx.x;
-    const bool have = i < n;
+    const uint32_t jr = i < n ? P.sh_idx[i] : 0xFFFFFFFFu;
+    const bool have = jr != 0xFFFFFFFFu;
     RayIn r = idle_ray();
     Hit h;
     h.t = INFINITY;
     h.id = -1;
     if (have) {
-      const size_t j = P.sh_idx[i];  // i-th ray in hit-point order: one 64-byte record
+      const size_t j = jr;  // i-th ray in hit-point order: one 64-byte record
       r = load_queued_ray(P, j);
       const float4 q3 = P.q_in[j * RT_QUEUE_QUADS + 3u];
       h.t = q3.x;
@@ -2258,7 +2261,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
 
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_shade_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
-  __shared__ unsigned long long lds_cnt[20];  // 15 counters (wave_flush), [16..19]: wave start times (cost calibration)
+  __shared__ unsigned long long lds_cnt[20];
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
     shade_body<true>(sc, P, lds_stash, lds_cnt);
   else

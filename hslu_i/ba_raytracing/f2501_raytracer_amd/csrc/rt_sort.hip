@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void rt_sort_place_kernel(RtDevParams P) {
   uint32_t n = *(const uint32_t*)P.q_in_count;
   n = n < P.q_capacity ? n : P.q_capacity;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const float4 q3 = P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u];  // {t, hit id, bucket, rank}
+    const float4 q3 = P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u];  // {t, hit id, Morton key, rank}
     if (__float_as_int(q3.y) < 0) continue;                      // a miss: not shaded
-    const uint32_t b = __float_as_uint(q3.z);
+    const uint32_t b = __float_as_uint(q3.z) >> (30u - P.sort_bits);
     P.sh_idx[P.sort_tile[b / RT_SORT_TILE] + P.sort_offs[b] + __float_as_uint(q3.w)] = i;
   }
 }

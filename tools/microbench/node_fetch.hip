@@ -9,6 +9,9 @@
 //           broadcast) + v_readfirstlane of the two child indices; box planes stay in VGPRs
 //   mode 3  as 0 with a BVH4-shaped step: ONE 128-byte fetch (2 x s_load_dwordx16), 4 boxes tested, i.e. half as many
 //           dependent steps for the same number of boxes
+//   mode 4  vector loads with a wave-uniform address (4 x global_load_dwordx4 through the vector L1, node lands in VGPRs)
+//   mode 5  BVH4-shaped step from LDS (8 x ds_read_b128)
+//   mode 6  BVH4-shaped step through vector loads (8 x global_load_dwordx4, uniform address)
 // Reported: nanoseconds per step of ONE wave (latency, 1 wave per SIMD) and per step per SIMD with 6 resident waves
 // (what the other waves can hide).
 // Build: hipcc --offload-arch=gfx950 -O3 -o node_fetch node_fetch.hip ; run on the GPU box.
@@ -50,7 +53,7 @@ __device__ __forceinline__ unsigned long long slab(const float* lo, const float*
 template <int MODE>
 __global__ __launch_bounds__(256) void walk(const Node* __restrict__ nodes, uint32_t mask, int steps, uint32_t* out) {
   __shared__ Node lds[64];
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 5) {
     if (threadIdx.x < 64) lds[threadIdx.x] = nodes[threadIdx.x];
     __syncthreads();
   }
@@ -71,6 +74,29 @@ __global__ __launch_bounds__(256) void walk(const Node* __restrict__ nodes, uint
       acc += h0 ^ h1;
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_uint(a.w)), c1 = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
       idx = (h0 ? c0 : c1) & mask;
+    } else if (MODE == 4) {
+      const float4* p = (const float4*)&nodes[__builtin_amdgcn_readfirstlane(idx)];
+      float4 a = p[0], b = p[1], c = p[2], d = p[3];  // global_load_dwordx4 x 4, every lane the same address
+      asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x));  // (keep them vector loads)
+      const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z}, lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
+      const unsigned long long h0 = slab(lo0, hi0, ix, iy, iz, nx, ny, nz), h1 = slab(lo1, hi1, ix, iy, iz, nx, ny, nz);
+      acc += h0 ^ h1;
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_uint(a.w)), c1 = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+      idx = (h0 ? c0 : c1) & mask;
+    } else if (MODE == 5 || MODE == 6) {
+      const uint32_t i0 = __builtin_amdgcn_readfirstlane(idx), i1 = (i0 + 1u) & mask;
+      const float4* p = MODE == 5 ? (const float4*)&lds[i0] : (const float4*)&nodes[i0];
+      const float4* q = MODE == 5 ? (const float4*)&lds[i1] : (const float4*)&nodes[i1];
+      float4 a = p[0], b = p[1], c = p[2], d = p[3], e = q[0], f = q[1], g = q[2], h = q[3];
+      if (MODE == 6) asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x), "+v"(e.x), "+v"(f.x), "+v"(g.x), "+v"(h.x));
+      const float l0[3] = {a.x, a.y, a.z}, u0[3] = {b.x, b.y, b.z}, l1[3] = {c.x, c.y, c.z}, u1[3] = {d.x, d.y, d.z};
+      const float l2[3] = {e.x, e.y, e.z}, u2[3] = {f.x, f.y, f.z}, l3[3] = {g.x, g.y, g.z}, u3[3] = {h.x, h.y, h.z};
+      const unsigned long long h0 = slab(l0, u0, ix, iy, iz, nx, ny, nz), h1 = slab(l1, u1, ix, iy, iz, nx, ny, nz);
+      const unsigned long long h2 = slab(l2, u2, ix, iy, iz, nx, ny, nz), h3 = slab(l3, u3, ix, iy, iz, nx, ny, nz);
+      acc += h0 ^ h1 ^ h2 ^ h3;
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_uint(a.w)), c1 = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+      const uint32_t c2 = __builtin_amdgcn_readfirstlane(__float_as_uint(e.w)), c3 = __builtin_amdgcn_readfirstlane(__float_as_uint(g.w));
+      idx = (h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3))) & mask;
     } else {
       const Node na = uload(&nodes[idx]), nb = uload(&nodes[(idx + 1u) & mask]);  // one 128-byte BVH4 node
       const unsigned long long h0 = slab(na.lo0, na.hi0, ix, iy, iz, nx, ny, nz), h1 = slab(na.lo1, na.hi1, ix, iy, iz, nx, ny, nz);
@@ -114,11 +140,15 @@ int main() {
   Node* d;
   hipMalloc(&d, sizeof(Node) * n_big);
   hipMemcpy(d, h.data(), sizeof(Node) * n_big, hipMemcpyHostToDevice);
-  for (int w : {1, 6}) {
+  for (int w : {1, 3, 6}) {
     run<0>("s_load x16, 4 KiB table (scalar-cache hit)", d, n_small - 1, w);
     run<1>("s_load x16, 8 MiB table (scalar miss, L2 hit)", d, n_big - 1, w);
     run<2>("LDS ds_read_b128 x4 + readfirstlane", d, n_small - 1, w);
     run<3>("BVH4 step: 2 x s_load x16, 4 boxes (hit)", d, n_small - 1, w);
+    run<4>("vector loads, uniform address, 4 KiB table", d, n_small - 1, w);
+    run<4>("vector loads, uniform address, 8 MiB table", d, n_big - 1, w);
+    run<5>("BVH4 step from LDS (8 x ds_read_b128)", d, n_small - 1, w);
+    run<6>("BVH4 step, vector loads, 4 KiB table", d, n_small - 1, w);
   }
   hipFree(d);
   return 0;
