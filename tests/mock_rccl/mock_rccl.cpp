@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -28,6 +29,7 @@ struct Op {
   ncclComm* comm;
   hipStream_t stream;
   bool used = false;
+  hipEvent_t ready = nullptr;  // deferred mode: recorded on the sender's stream when the send was posted
 };
 std::mutex g_mu;
 int g_depth = 0;
@@ -38,22 +40,30 @@ ncclResult_t bad(const char* m) {
   fprintf(stderr, "%s\n", g_msg);
   return ncclInvalidUsage;
 }
+// MOCK_RCCL_DEFER=1: one process plays several process-per-GPU ranks one after the other (rt_render_gather_device is
+// called rank by rank, each call its own ncclGroup): an operation whose partner has not been posted yet stays pending
+// instead of failing the group, as a real send / receive would wait on its stream for the peer.
+bool deferred() {
+  static const bool d = getenv("MOCK_RCCL_DEFER") != nullptr;
+  return d;
+}
 ncclResult_t flush() {
   // match every receive with its send and move the bytes (stream ordered: the receive waits for the sender's stream)
   for (Op& r : g_ops) {
-    if (r.send) continue;
+    if (r.send || r.used) continue;
     Op* s = nullptr;
     for (Op& c : g_ops)
       if (c.send && !c.used && c.comm->rank == r.peer && c.peer == r.comm->rank) {
         s = &c;
         break;
       }
+    if (!s && deferred()) continue;  // the sender has not called yet
     if (!s) return bad("a receive has no matching send");
     if (s->count != r.count || s->type != r.type) return bad("send / receive sizes differ");
     if (r.type != ncclUint32) return bad("unexpected data type");
-    hipEvent_t ev;
-    if (hipSetDevice(s->comm->dev) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventRecord(ev, s->stream) != hipSuccess)
+    hipEvent_t ev = s->ready;
+    if (!ev && (hipSetDevice(s->comm->dev) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(ev, s->stream) != hipSuccess))
       return bad("event on the sender's stream failed");
     if (hipSetDevice(r.comm->dev) != hipSuccess || hipStreamWaitEvent(r.stream, ev, 0) != hipSuccess ||
         hipMemcpyAsync(r.buf, s->buf, r.count * 4, hipMemcpyDeviceToDevice, r.stream) != hipSuccess)
@@ -61,8 +71,20 @@ ncclResult_t flush() {
     (void)hipEventDestroy(ev);
     s->used = r.used = true;
   }
+  size_t pending = 0;
   for (Op& c : g_ops)
-    if (!c.used) return bad("a send has no matching receive");
+    if (!c.used) {
+      if (!deferred()) return bad("a send has no matching receive");
+      pending++;
+    }
+  if (deferred()) {
+    std::vector<Op> keep;
+    for (Op& c : g_ops)
+      if (!c.used) keep.push_back(c);
+    fprintf(stderr, "mock RCCL: %zu operations matched, %zu pending\n", g_ops.size() - pending, pending);
+    g_ops.swap(keep);
+    return ncclSuccess;
+  }
   fprintf(stderr, "mock RCCL: group of %zu operations matched\n", g_ops.size());
   g_ops.clear();
   return ncclSuccess;
@@ -118,7 +140,13 @@ ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int pe
   std::lock_guard<std::mutex> l(g_mu);
   if (g_depth <= 0) return bad("ncclSend outside a group");
   if (peer < 0 || peer >= comm->n || peer == comm->rank) return bad("ncclSend: bad peer");
-  g_ops.push_back(Op{true, const_cast<void*>(buf), count, type, peer, comm, stream});
+  Op op{true, const_cast<void*>(buf), count, type, peer, comm, stream};
+  if (deferred()) {  // the data is complete at this point of the sender's stream
+    if (hipSetDevice(comm->dev) != hipSuccess || hipEventCreateWithFlags(&op.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(op.ready, stream) != hipSuccess)
+      return bad("event on the sender's stream failed");
+  }
+  g_ops.push_back(op);
   return ncclSuccess;
 }
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {

@@ -1159,3 +1159,115 @@ def test_streaming_frames_are_enqueued_without_waiting_for_the_gpu():
     g.close()
     ds.close()
     assert hip.hipStreamDestroy(stream) == 0 and hip.hipFree(fb) == 0
+
+
+MOCK_RCCL_PER_RANK_CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, _abi, _lib, scenes
+from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene, ImageBuffer, RaytracerRenderer
+lib = _lib.load()
+hip = lib  # (dlsym on the library's handle searches its dependencies: the HIP runtime it is linked against)
+cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], n_cloud_sets=16)
+flat = scenes.test_scene(cfg).flatten()
+npix, nbytes = cfg.width * cfg.height, cfg.width * cfg.height * 4
+fill = 0x00A1B2C3
+ref = ImageBuffer.new_with_color(cfg.width, cfg.height, fill)
+RaytracerRenderer(cfg, device=0).render(ref, flat)
+N = 3
+ident = (C.c_uint8 * _abi.RT_COMM_ID_BYTES)()
+_lib.check(lib.rt_comm_unique_id(ident))
+comms, scenes_, streams = [], [], []
+for r in range(N):
+    h = C.c_void_p()
+    _lib.check(lib.rt_comm_create(ident, N, r, 0, C.byref(h)))
+    comms.append(h)
+    scenes_.append(DeviceScene(flat, 0))
+    pair = []
+    for _ in range(2):
+        sp = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(sp), 1) == 0
+        pair.append(sp)
+    streams.append(pair)
+fbs = []
+for _ in range(2):
+    fp = C.c_void_p()
+    assert hip.hipMalloc(C.byref(fp), C.c_size_t(nbytes)) == 0
+    fbs.append(fp)
+host_fill = np.full(npix, fill, np.uint32)
+p, keep = _abi.make_params(cfg, n_ranks=99, rank=7)  # (ignored: the communicators' are used)
+
+def fetch(i):
+    got = np.zeros(npix, np.uint32)
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fbs[i], C.c_size_t(nbytes), 2) == 0
+    return got
+
+# two frames in flight, each rank's calls one after the other as separate processes would make them (peers first)
+for rep in range(3):
+    for fb in fbs:
+        assert hip.hipMemcpy(fb, C.c_void_p(host_fill.ctypes.data), C.c_size_t(nbytes), 1) == 0
+    for f in range(2):
+        for r in (2, 1, 0):
+            _lib.check(lib.rt_render_gather_device(scenes_[r].handle, comms[r], C.byref(p), fbs[f] if r == 0 else None, streams[r][f]))
+    assert hip.hipDeviceSynchronize() == 0
+    for f in range(2):
+        bad = int((fetch(f) != ref.buffer).sum())
+        print("rep", rep, "frame", f, "differing pixels", bad, flush=True)
+        assert bad == 0
+info = _abi.rt_gather_info()
+_lib.check(lib.rt_comm_last_gather(comms[1], C.byref(info)))
+assert info.bytes_sent > 0 and info.n_ranks == N and info.rank == 1 and info.transport == _abi.RT_TRANSPORT_RCCL
+
+# a rank whose render fails still takes part in the gather (zeroed tiles) and reports the error afterwards
+tab = np.random.default_rng(1).uniform(-1e-3, 1e-3, (300, 2)).astype(np.float32)
+p_bad, keep_bad = _abi.make_params(cfg, aa_offsets=tab)  # aa_rays > 256: refused when the frame is prepared
+assert hip.hipMemcpy(fbs[0], C.c_void_p(host_fill.ctypes.data), C.c_size_t(nbytes), 1) == 0
+rc2 = lib.rt_render_gather_device(scenes_[2].handle, comms[2], C.byref(p), None, streams[2][0])
+rc1 = lib.rt_render_gather_device(scenes_[1].handle, comms[1], C.byref(p_bad), None, streams[1][0])
+msg1 = lib.rt_last_error().decode()
+rc0 = lib.rt_render_gather_device(scenes_[0].handle, comms[0], C.byref(p), fbs[0], streams[0][0])
+assert hip.hipDeviceSynchronize() == 0
+print("failing rank:", rc2, rc1, msg1, rc0, flush=True)
+assert rc2 == 0 and rc0 == 0 and rc1 == _abi.RT_ERR_UNSUPPORTED and "aa_rays" in msg1
+from hslu_i.ba_raytracing.f2501_raytracer_amd.distributed import tile_owner_map
+own = np.repeat(np.repeat(tile_owner_map(cfg, N), 48, axis=0), 48, axis=1)[:cfg.height, :cfg.width].ravel()
+got = fetch(0)
+assert np.array_equal(got[own != 1], ref.buffer[own != 1]) and (got[own == 1] == fill).all()
+
+# a rank that cannot set the frame up aborts its communicator instead of leaving the peers in the gather
+p_zero, keep_zero = _abi.make_params(cfg)
+p_zero.width = 0
+rc = lib.rt_render_gather_device(scenes_[1].handle, comms[1], C.byref(p_zero), None, streams[1][0])
+msg = lib.rt_last_error().decode()
+print("abort:", rc, msg, flush=True)
+assert rc == _abi.RT_ERR_INVALID_ARG and "communicator aborted" in msg
+rc = lib.rt_render_gather_device(scenes_[1].handle, comms[1], C.byref(p), None, streams[1][0])
+assert rc != 0 and "aborted" in lib.rt_last_error().decode()
+print("MOCK-RCCL-PER-RANK-OK", flush=True)
+"""
+
+
+def test_render_gather_device_three_ranks_two_frames_in_flight_and_failing_ranks(tmp_path):
+    """The process-per-GPU entry point with MORE THAN ONE rank -- rt_comm_create x 3, rt_render_gather_device rank by rank,
+    two frames in flight (double-buffered staging, gather stream) -- on a one-GPU box: a child process preloads
+    tests/mock_rccl in its deferred mode (an operation whose partner has not called yet stays pending, as a real
+    send / receive waits on its stream) and plays the three ranks one after the other.  The gathered frames must equal the
+    single-GPU frame.  Then the failure paths: a rank whose render fails still sends its (zeroed) tiles and returns its
+    error afterwards, its peers complete; a rank that cannot set the frame up aborts the communicator."""
+    import shutil
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc to build the mock")
+    so = tmp_path / "librccl_mock.so"
+    subprocess.check_call([hipcc, "-O1", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", "-o", str(so),
+                           os.path.join(here, "mock_rccl", "mock_rccl.cpp")])
+    env = dict(os.environ, LD_PRELOAD=str(so), MOCK_RCCL_DEFER="1")
+    out = subprocess.run([sys.executable, "-c", MOCK_RCCL_PER_RANK_CHILD.format(root=root, tests=here)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MOCK-RCCL-PER-RANK-OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "ncclCommAbort(rank 1)" in out.stderr and "sizes differ" not in out.stderr
