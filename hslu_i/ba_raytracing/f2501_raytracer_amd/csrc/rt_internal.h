@@ -183,6 +183,12 @@ struct RtDevParams {
 #define RT_SORT_BITS_DEFAULT 22u
 #define RT_COUNTER_REPLICAS 64u
 
+// primary kernel: do the n_thr sample threads of a pixel share one wavefront (wasting at most 4 of its lanes)?
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline bool rt_primary_wave_local(uint32_t n_thr) { return n_thr <= 64u && (64u / n_thr) * n_thr >= 60u; }
+
 // kernel launchers (rt_kernels.hip); return hipError_t as int
 uint32_t rt_primary_pixels_per_wg(const RtDevParams& p);
 uint32_t rt_primary_total_wgs(const RtDevParams& p);

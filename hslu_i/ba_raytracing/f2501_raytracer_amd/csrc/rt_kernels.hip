@@ -1270,15 +1270,23 @@ __device__ __forceinline__ void wave_init(Wave& w) {
 #endif
 }
 
-// Statistics: the wavefronts of a workgroup add their counters in LDS, then 14 threads issue one global
+// Statistics: the wavefronts of a workgroup add their counters in LDS, then 15 threads issue one global
 // atomic each (RT_COUNTER_REPLICAS copies on separate 128-B lines keep the per-line atomic rate off the
-// critical path; the host sums them).  Every thread of the workgroup must call this (two barriers).
+// critical path; the host sums them).
 #define RT_N_COUNTERS 15u
+// Every thread of the workgroup calls wave_flush_init once at the START of the kernel (one barrier, where nobody waits for
+// anybody); wave_flush itself has no barrier: a wavefront adds its counters to the workgroup's sums in LDS and counts
+// itself done, and the wavefront that arrives LAST hands the sums to the global replicas.  A wavefront that is done
+// therefore ends at once -- it does not sit on its registers until the slowest of its workgroup has finished.
+__device__ __forceinline__ void wave_flush_init(const RtDevParams& P, unsigned long long* lds_cnt) {
+  if (!P.counters) return;  // wave-uniform (kernel argument)
+  if (threadIdx.x < 16u) lds_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+}
 __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, unsigned long long written,
                                            unsigned long long* lds_cnt) {
   if (!P.counters) return;  // wave-uniform (kernel argument)
-  if (threadIdx.x < RT_N_COUNTERS) lds_cnt[threadIdx.x] = 0ull;
-  __syncthreads();
+  uint32_t before = 0u;
   if ((threadIdx.x & 63u) == 0) {
 #if RT_PROFILE
     const unsigned long long v[RT_N_COUNTERS] = {w.cnt_kind[0], w.cnt_kind[1], w.cnt_kind[2], w.cnt_shadow, written,
@@ -1292,11 +1300,13 @@ __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, 
 #pragma unroll
     for (unsigned i = 0; i < RT_N_COUNTERS; i++)
       if (v[i]) atomicAdd(&lds_cnt[i], v[i]);
+    before = (uint32_t)atomicAdd(&lds_cnt[15], 1ull);  // (returns after the adds above: LDS serves a wavefront in order)
   }
-  __syncthreads();
-  if (threadIdx.x < RT_N_COUNTERS) {
-    unsigned long long v = lds_cnt[threadIdx.x];
-    if (v) atomicAdd(&P.counters[(size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u + threadIdx.x], v);
+  before = __builtin_amdgcn_readfirstlane(before);
+  if (before + 1u == (blockDim.x >> 6) && (threadIdx.x & 63u) < RT_N_COUNTERS) {
+    const uint32_t i = threadIdx.x & 63u;
+    unsigned long long v = lds_cnt[i];
+    if (v) atomicAdd(&P.counters[(size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u + i], v);
   }
 }
 
@@ -1920,6 +1930,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
                                              float* lds_stash, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
+  wave_flush_init(P, lds_cnt);
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
   const uint32_t n_samples = aa ? P.aa_rays : 1u;  // samples of the reference's per-pixel sum
   const uint32_t n_thr = aa ? P.aa_unique : 1u;    // threads per pixel (distinct samples)
@@ -1930,16 +1941,30 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
     uint32_t slot, k, gx, gy, pix;
     bool on;
   };
+  // The samples of a pixel sit in ONE wavefront whenever that wastes at most 4 lanes (9 distinct samples: 7 pixels on 63
+  // lanes): the per-pixel sum then needs no workgroup barrier, and a wavefront that is done leaves the CU without waiting
+  // for the slowest of its workgroup (rt_primary_wave_local is the host's copy of this rule).
+  const bool wave_local = rt_primary_wave_local(n_thr);
+  const uint32_t ppwave = wave_local ? 64u / n_thr : 0u;
   auto map_thread = [&](uint32_t tid) {
     PixelMap m;
-    const uint32_t ppw = 256u / n_thr;  // pixels per workgroup (host guarantees n_thr <= 256)
-    m.slot = tid / n_thr;
-    m.k = tid - m.slot * n_thr;
+    const uint32_t ppw = wave_local ? 4u * ppwave : 256u / n_thr;  // pixels per workgroup (host guarantees n_thr <= 256)
+    bool slot_used;
+    if (wave_local) {
+      const uint32_t ln = tid & 63u, in_wave = ln / n_thr;
+      m.k = ln - in_wave * n_thr;
+      m.slot = (tid >> 6) * ppwave + in_wave;
+      slot_used = in_wave < ppwave;
+    } else {
+      m.slot = tid / n_thr;
+      m.k = tid - m.slot * n_thr;
+      slot_used = m.slot < ppw;
+    }
     const uint32_t st_x = (P.win_w + 15u) / 16u;
     const uint32_t wg = P.batch_first_wg + blockIdx.x;
     const uint32_t g = wg * ppw + m.slot;  // pixel ordinal in super-tile order
     const uint32_t sup_slot = g >> 8, in_sup = g & 255u;
-    const bool lane_used = (m.slot < ppw) && (sup_slot < P.n_sup);
+    const bool lane_used = slot_used && (sup_slot < P.n_sup);
     uint32_t sup = sup_slot;
     if (P.sup_list) sup = lane_used ? P.sup_list[sup_slot] : 0u;
     const uint32_t t4 = (in_sup >> 4) & 15u, p4 = in_sup & 15u;
@@ -1985,19 +2010,26 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   uint32_t tid2 = threadIdx.x;
   RT_OPAQUE(tid2);  // keeps hipcc from carrying the first mapping through process_ray
   const PixelMap pm2 = map_thread(tid2);
-  const uint32_t pix = pm2.pix, slot = pm2.slot;
+  const uint32_t pix = pm2.pix;
   if (pm2.k == 0 && pm2.on) {
     if (P.aux_hit_id) P.aux_hit_id[pix] = out.id;
     if (P.aux_hit_t && out.id >= 0) P.aux_hit_t[pix] = out.t;
   }
-  __syncthreads();
+  // the samples of a pixel are the threads tid2 .. tid2 + n_thr - 1 (tid2 = the pixel's thread with k == 0)
+  if (wave_local) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
   bool wrote = false;
   if (STREAM && pm2.k == 0 && pm2.on) {
     // Secondary rays are streaming: the pixel is resolved by rt_resolve_kernel from the fixed-point accumulator.  The
     // samples' own terms are already integers (process_ray); a sample the reference casts m times adds m x its sum --
     // exact, whatever the order, so tracing each distinct sample once changes no bit of the frame.
-    const float4* s = lds_rgbh + slot * n_thr;
-    const long long* fx = stash_fix(lds_stash) + slot * n_thr;
+    const float4* s = lds_rgbh + tid2;
+    const long long* fx = stash_fix(lds_stash) + tid2;
     long long sx = 0, sy = 0, sz = 0;
     bool any = false;
     for (uint32_t u = 0; u < n_thr; u++) {
@@ -2014,7 +2046,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
     }
   }
   if (!STREAM && pm2.k == 0 && pm2.on) {
-    const float4* s = lds_rgbh + slot * n_thr;
+    const float4* s = lds_rgbh + tid2;
     // sample q of the reference's sum -> the thread that traced it (wave-uniform q: scalar load)
     auto src = [&](uint32_t q) { return P.weighted ? uload(&P.aa_src[q]) : q; };
     V3 color;
@@ -2066,7 +2098,8 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   }
   if (COST && P.cost_map && (threadIdx.x & 63u) == 0) {
     const unsigned long long dt = __builtin_readcyclecounter() - lds_cnt[16 + (threadIdx.x >> 6)];
-    const uint32_t ppw = 256u / n_thr, g = (P.batch_first_wg + blockIdx.x) * ppw + threadIdx.x / n_thr, sup_slot = g >> 8;
+    const uint32_t ppw = wave_local ? 4u * ppwave : 256u / n_thr;
+    const uint32_t g = (P.batch_first_wg + blockIdx.x) * ppw + (wave_local ? (threadIdx.x >> 6) * ppwave : threadIdx.x / n_thr), sup_slot = g >> 8;
     if (sup_slot < P.n_sup) atomicAdd(&P.cost_map[P.sup_list ? P.sup_list[sup_slot] : sup_slot], (uint32_t)(dt >> 6));
   }
   wave_flush(wv, P, (uint32_t)__popcll(wave_ballot(wrote)), lds_cnt);
@@ -2166,6 +2199,7 @@ template <bool CULL>
 __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevParams& P, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
+  wave_flush_init(P, lds_cnt);
   // how many rays this level holds is only known on the device (the kernel before appended them)
   uint32_t n = uload(P.q_in_count);
   n = n < P.q_capacity ? n : P.q_capacity;
@@ -2234,6 +2268,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
                                            unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
+  wave_flush_init(P, lds_cnt);
   const uint32_t n = uload(P.sort_hits);  // the rays of this level that hit something, in hit-point order (misses are not listed)
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + threadIdx.x;
@@ -2553,7 +2588,8 @@ int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, ui
 // ---- host-side launchers ---------------------------------------------------------------------------
 uint32_t rt_primary_pixels_per_wg(const RtDevParams& p) {
   const bool aa = (p.flags & RT_FLAG_ANTI_ALIASING) && p.aa_rays > 0;
-  return 256u / (aa ? p.aa_unique : 1u);
+  const uint32_t n_thr = aa ? p.aa_unique : 1u;
+  return rt_primary_wave_local(n_thr) ? 4u * (64u / n_thr) : 256u / n_thr;
 }
 
 // workgroups of the primary kernel: the 256 pixels of every (listed) 16x16 super-tile, ppw per workgroup
