@@ -12,9 +12,10 @@ ncclSend / ncclRecv group (C ABI: rt_comm_* / rt_render_gather_device) inside th
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Frames without secondary rays are enqueued on two streams alternately (two frames in flight, each into its own frame
-buffer): a launch cannot end before its longest wavefront does, and the head of the next frame fills the compute units
-that drain leaves idle.  Every timed step is a complete frame; the K steps are bracketed by barrier + synchronise.
+Frames are enqueued on two streams alternately (two frames in flight, each into its own frame buffer): a launch cannot
+end before its longest wavefront does, and the head of the next frame fills the compute units that drain leaves idle
+(a frame with secondary rays is a chain of such launches, one per ray-tree level).  Every timed step is a complete
+frame; the K steps are bracketed by barrier + synchronise.
 
 Rank 0 prints ONE JSON line.  `value` = (primary + reflection + refraction rays of one frame as the
 reference casts them, all ranks) / (max-over-ranks seconds per frame), in Mray/s; `value_traced` = the rays the GPU
@@ -197,6 +198,39 @@ def boundary_costs(cfg, flat, lib, _abi, _lib, device):
     }
 
 
+def time_workload(key, lib, _abi, _lib, DeviceScene, torch, dev, device_index, steps=8, warmup=2):
+    """ms per frame and Mray/s of another workload: `steps` frames back to back through rt_render_device on two streams
+    used alternately, HBM-resident frame buffers, wall clock between two synchronisations."""
+    cfg, flat, name = build_workload(key)
+    ds = DeviceScene(flat, device=device_index)
+    p, keep = _abi.make_params(cfg)
+    fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    n = [0]
+
+    def frame():  # two frames in flight, like the headline measurement
+        i = n[0] & 1
+        n[0] += 1
+        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fbs[i].data_ptr()), None, C.c_void_p(streams[i].cuda_stream)))
+
+    for _ in range(warmup):
+        frame()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    st = _abi.rt_stats()
+    _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
+    rays = st.rays_primary + st.rays_reflection + st.rays_refraction
+    out = {"workload": name, "steps": steps, "frames_in_flight": 2, "ms_per_step": sec * 1e3, "value": rays / sec / 1e6, "unit": "Mray/s",
+           "value_traced": st.rays_traced / sec / 1e6, "mshadow_per_s": st.rays_shadow / sec / 1e6, "rays_per_frame": rays,
+           "queue_bytes": int(st.queue_bytes), "notes": int(st.notes)}
+    ds.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,9 +239,11 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary-costs", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run (config 3, one GPU): skip the short timings of configs 4 and 5 appended as `other_workloads`")
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
-                    help="frames in flight (streams used alternately).  0 = 2 for frames without secondary rays (the head of a "
-                         "frame fills the CUs the drain of the one before leaves idle), 1 otherwise")
+                    help="frames in flight (streams used alternately).  0 = 2: the head of a frame fills the CUs the drain of the one "
+                         "before leaves idle (frames with secondary rays: every ray-tree level is a launch with a drain of its own)")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
@@ -243,8 +279,7 @@ def main():
     scene_create_ms = (time.perf_counter() - t_scene) * 1e3
     p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank)
     npix = cfg.width * cfg.height
-    secondary = cfg.has("reflections") or cfg.has("refractions")
-    n_fly = args.in_flight or (1 if secondary else 2)
+    n_fly = args.in_flight or 2
     if args.backend == "gloo" and world > 1:
         n_fly = 1  # (the host rehearsal synchronises every frame)
     # one frame buffer and one stream per frame in flight (a displayed sequence is double buffered anyway)
@@ -435,6 +470,9 @@ def main():
             out["config"]["mray_per_s_incl_d2h"] = rays / (sec_per_step + out["d2h_ms"] * 1e-3) / 1e6
             if not args.no_boundary_costs:
                 out["boundary"] = boundary_costs(cfg, flat, lib, _abi, _lib, local_rank)
+        if world == 1 and args.workload == "c3" and not args.no_other_workloads:
+            # the other BASELINE configs under the same clock (a few frames each; their own bench lines: --workload c4 / c5)
+            out["other_workloads"] = {k: time_workload(k, lib, _abi, _lib, DeviceScene, torch, dev, local_rank) for k in ("c4", "c5")}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, flat)
             out["cpu_baseline"]["gpu_over_cpu"] = mrays / out["cpu_baseline"]["value"]

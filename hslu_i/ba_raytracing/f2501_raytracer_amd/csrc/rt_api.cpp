@@ -72,10 +72,12 @@ void rt_scene_destroy(rt_scene* s) {
   if (s->tables_ev) (void)hipEventDestroy(s->tables_ev);
   for (hipEvent_t e : s->frame_ev)
     if (e) (void)hipEventDestroy(e);
-  if (s->cnt_ev) (void)hipEventDestroy(s->cnt_ev);
-  if (s->cnt_host) (void)hipHostFree(s->cnt_host);
-  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->queues, &s->qcount, &s->acc, &s->suplist, &s->trace_ws, &s->sort_tmp, &s->hard, &s->fb, &s->aux_rgb, &s->costmap,
-                    &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags})
+  for (auto& w : s->ws) {
+    if (w.cnt_ev) (void)hipEventDestroy(w.cnt_ev);
+    if (w.cnt_host) (void)hipHostFree(w.cnt_host);
+    for (DevBuf* b : {&w.queues, &w.qcount, &w.acc, &w.trace_ws, &w.hard}) b->release();
+  }
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags})
     b->release();
   delete s;
 }
@@ -596,14 +598,15 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     P->aux_hit_t = aux_dev->hit_t;
   }
   {
-    // this frame's counter block: wait for the frame that used it last (two frames may be in flight on two streams);
-    // a frame with secondary rays also owns the queues and the accumulator: it waits for both
-    const int blk = (int)(s->frame_no++ & 1u);
-    const bool secondary = (p->flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
+    // this frame's slot (counter block + workspace set): one whose last frame has finished if there is one, else the one
+    // used longest ago -- whose frame this stream then waits for
     for (int b = 0; b < 2; b++) {
       if (!s->frame_ev[b]) HIP_TRY(hipEventCreateWithFlags(&s->frame_ev[b], hipEventDisableTiming));
-      if (s->frame_pending[b] && (b == blk || secondary)) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[b], 0));
+      if (s->frame_pending[b] && hipEventQuery(s->frame_ev[b]) == hipSuccess) s->frame_pending[b] = false;
     }
+    int blk = !s->frame_pending[0] ? 0 : (!s->frame_pending[1] ? 1 : (s->frame_seq[0] <= s->frame_seq[1] ? 0 : 1));
+    if (s->frame_pending[blk]) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[blk], 0));
+    s->frame_seq[blk] = ++s->frame_no;
     s->cur_block = blk;
     unsigned long long* blk_p = (unsigned long long*)s->counters.p + (size_t)blk * RT_COUNTER_REPLICAS * 16;
     P->counters = p->tuning.no_counters ? nullptr : blk_p;
@@ -703,7 +706,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
 // the accumulator dirty so that the next frame clears it.
 static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking = false) {
   const int rc = render_frame_impl(s, P, stream, forced_chunk_log2, blocking);
-  if (rc != RT_OK) s->acc_pixels = 0;
+  if (rc != RT_OK) s->ws[s->cur_ws].acc_pixels = 0;
   // marks the end of this frame's use of its counter block (prepare() of a later frame waits for it)
   if (hipEventRecord(s->frame_ev[s->cur_block], stream) == hipSuccess) s->frame_pending[s->cur_block] = true;
   s->last_block = s->cur_block;
@@ -731,9 +734,22 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const bool hard = P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);
-  if ((rc = s->qcount.ensure((size_t)n_cnt * 4)) != RT_OK) return rc;
-  if (!s->cnt_host) HIP_TRY(hipHostMalloc((void**)&s->cnt_host, 160 * 4, hipHostMallocDefault));
-  if (!s->cnt_ev) HIP_TRY(hipEventCreateWithFlags(&s->cnt_ev, hipEventDisableTiming));
+  // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
+  // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
+  int wsi = s->cur_block;
+  if (wsi == 1 && !s->ws[1].queues.p && s->ws[0].queues.p) {
+    size_t free_b = 0, total_b = 0;
+    const size_t one_set = s->ws[0].queues.cap + s->ws[0].trace_ws.cap + s->ws[0].hard.cap + s->ws[0].acc.cap;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * one_set) wsi = 0;
+  }
+  if (s->ws_last_block[wsi] != s->cur_block && s->frame_pending[s->ws_last_block[wsi]])
+    HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[s->ws_last_block[wsi]], 0));
+  s->ws_last_block[wsi] = s->cur_block;
+  s->cur_ws = wsi;
+  rt_scene::StreamWs& w = s->ws[wsi];
+  if ((rc = w.qcount.ensure((size_t)n_cnt * 4)) != RT_OK) return rc;
+  if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, 160 * 4, hipHostMallocDefault));
+  if (!w.cnt_ev) HIP_TRY(hipEventCreateWithFlags(&w.cnt_ev, hipEventDisableTiming));
 
   // ---- the shape of this frame: what its ray counts depend on.  Same key as the last verified frame = same counts.
   StreamKey key;
@@ -753,10 +769,11 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->q_cap = s->hard_cap = s->batch_items = 0;
   }
   // the counts of an earlier frame of this shape, if their read-back has landed
-  if (s->cnt_pending && hipEventQuery(s->cnt_ev) == hipSuccess) {
-    s->cnt_pending = false;
-    if (s->cnt_host_levels == levels && s->cnt_host_valid) memcpy(s->est, s->cnt_host, n_cnt * 4), s->est_valid = true;
-  }
+  for (auto& o : s->ws)
+    if (o.cnt_pending && hipEventQuery(o.cnt_ev) == hipSuccess) {
+      o.cnt_pending = false;
+      if (o.cnt_host_levels == levels && o.cnt_host_valid) memcpy(s->est, o.cnt_host, n_cnt * 4), s->est_valid = true;
+    }
 
   for (int attempt = 0;; attempt++) {
     // ---- sizes.  Unknown shape: every level fits the primary work items (children usually thin out; a scene where
@@ -773,7 +790,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       s->hard_cap = hard ? std::max<uint32_t>(s->q_cap / 8u, 1u << 16) : 0u;
     }
     size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
-    const size_t held = s->queues.cap + s->hard.cap + s->trace_ws.cap;
+    const size_t held = w.queues.cap + w.hard.cap + w.trace_ws.cap;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
     auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)(q * (2u * 64u + 4u) + (h ? (h + 64u) * 64u : 0u)); };
     while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
@@ -786,45 +803,46 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->batch_items = (s->batch_items + 255u) / 256u * 256u;
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : RT_SORT_BITS_DEFAULT;
     const uint32_t n_buckets = 1u << P.sort_bits;
-    rc = s->queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
-    if (rc == RT_OK) rc = s->trace_ws.ensure((size_t)s->q_cap * 4 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
-    if (rc == RT_OK && hard) rc = s->hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
+    rc = w.queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
+    if (rc == RT_OK) rc = w.trace_ws.ensure((size_t)s->q_cap * 4 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+    if (rc == RT_OK && hard) rc = w.hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
       s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
       s->batch_items = std::max<uint32_t>(s->batch_items / 2u, 1u << 10);
       continue;
     }
     if (rc != RT_OK) return rc;
-    if (s->acc_pixels != npix) {
-      if ((rc = s->acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
-      HIP_TRY(hipMemsetAsync(s->acc.p, 0, npix * 4 * sizeof(long long), stream));
-      s->acc_pixels = npix;
+    if (w.acc_pixels != npix) {
+      if ((rc = w.acc.ensure(npix * 4 * sizeof(long long))) != RT_OK) return rc;
+      HIP_TRY(hipMemsetAsync(w.acc.p, 0, npix * 4 * sizeof(long long), stream));
+      w.acc_pixels = npix;
     }
-    uint32_t* ws = (uint32_t*)s->trace_ws.p;
+    uint32_t* ws = (uint32_t*)w.trace_ws.p;
     P.sh_idx = ws;
     P.sort_hist = ws + s->q_cap;
     P.sort_offs = P.sort_hist + n_buckets;
     P.sort_tile = P.sort_offs + n_buckets;
-    if (s->sort_hist_clean != (void*)P.sort_hist || s->sort_hist_buckets != n_buckets) {
+    if (w.sort_hist_clean != (void*)P.sort_hist || w.sort_hist_buckets != n_buckets) {
       // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
       HIP_TRY(hipMemsetAsync(P.sort_hist, 0, (size_t)n_buckets * 4, stream));
-      s->sort_hist_clean = (void*)P.sort_hist;
-      s->sort_hist_buckets = n_buckets;
+      w.sort_hist_clean = (void*)P.sort_hist;
+      w.sort_hist_buckets = n_buckets;
     }
-    s->queue_bytes = s->queues.cap + s->trace_ws.cap + (hard ? s->hard.cap : 0);
+    s->queue_bytes = 0;
+    for (auto& o : s->ws) s->queue_bytes += o.queues.cap + o.trace_ws.cap + o.hard.cap + o.acc.cap;
     const uint32_t n_batches = (uint32_t)((items + s->batch_items - 1) / s->batch_items);
     if (n_batches > 1) s->notes |= RT_NOTE_FRAME_BATCHED;
 
-    uint32_t* counts = (uint32_t*)s->qcount.p;
+    uint32_t* counts = (uint32_t*)w.qcount.p;
     HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_cnt * 4, stream));
-    P.acc = (long long*)s->acc.p;
+    P.acc = (long long*)w.acc.p;
     P.q_capacity = s->q_cap;
     P.q_overflow = counts + RT_CNT_OVERFLOW;
-    P.hard_q = hard ? (float4*)s->hard.p : nullptr;
+    P.hard_q = hard ? (float4*)w.hard.p : nullptr;
     P.hard_capacity = s->hard_cap;
     P.hard_count = counts + RT_CNT_HARD(levels);
     P.hard_stat = counts + RT_CNT_HARD_STAT(levels);
-    float4* const q[2] = {(float4*)s->queues.p, (float4*)s->queues.p + (size_t)s->q_cap * RT_QUEUE_QUADS};
+    float4* const q[2] = {(float4*)w.queues.p, (float4*)w.queues.p + (size_t)s->q_cap * RT_QUEUE_QUADS};
     const uint32_t cap_wgs = (s->q_cap + 255u) / 256u;
     const bool guess = s->est_valid && n_batches == 1;  // grids from the previous frame's counts (else: whole capacity)
     const uint32_t ppw = 64u / (P.light_mult < 2u ? 2u : P.light_mult), pairs_per_wg = 4u * (ppw ? ppw : 1u);
@@ -874,24 +892,24 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
 
     // ---- the frame's counters come back asynchronously (grids of the next frame); an unverified shape waits for them
-    if (s->cnt_pending && (!s->stream_verified || blocking)) {  // (an older read-back still owns the pinned buffer)
-      HIP_TRY(hipEventSynchronize(s->cnt_ev));
-      s->cnt_pending = false;
+    if (w.cnt_pending && (!s->stream_verified || blocking)) {  // (an older read-back still owns the pinned buffer)
+      HIP_TRY(hipEventSynchronize(w.cnt_ev));
+      w.cnt_pending = false;
     }
-    if (!s->cnt_pending) {
-      HIP_TRY(hipMemcpyAsync(s->cnt_host, counts, (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipEventRecord(s->cnt_ev, stream));
-      s->cnt_pending = true;
-      s->cnt_host_levels = levels;
-      s->cnt_host_valid = n_batches == 1;
+    if (!w.cnt_pending) {
+      HIP_TRY(hipMemcpyAsync(w.cnt_host, counts, (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(w.cnt_ev, stream));
+      w.cnt_pending = true;
+      w.cnt_host_levels = levels;
+      w.cnt_host_valid = n_batches == 1;
     }
     if (s->stream_verified && !blocking) return RT_OK;
-    HIP_TRY(hipEventSynchronize(s->cnt_ev));
-    s->cnt_pending = false;
-    const uint32_t* c = s->cnt_host;
+    HIP_TRY(hipEventSynchronize(w.cnt_ev));
+    w.cnt_pending = false;
+    const uint32_t* c = w.cnt_host;
     const uint32_t dropped = c[RT_CNT_OVERFLOW], dropped_pairs = c[RT_CNT_HARD_STAT(levels)];
     if (!dropped && !dropped_pairs) {
-      if (s->cnt_host_valid) memcpy(s->est, c, n_cnt * 4), s->est_valid = true;
+      if (w.cnt_host_valid) memcpy(s->est, c, n_cnt * 4), s->est_valid = true;
       s->stream_verified = true;
       return RT_OK;
     }
@@ -909,7 +927,9 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       if (dropped_pairs) s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)s->hard_cap * 4u, 0xFFFFFF00ull);
     }
     s->est_valid = false;
-    s->acc_pixels = 0;  // partial sums: clear the accumulator
+    w.acc_pixels = 0;  // partial sums: clear the accumulator
+    // ... and the ray counters of the abandoned attempt (rt_stats counts what the reference casts, once)
+    if (P.counters) HIP_TRY(hipMemsetAsync(P.counters, 0, RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long), stream));
   }
 }
 

@@ -67,7 +67,20 @@ struct rt_scene {
   rt_bvh_info info{};
   DevBuf blob;  // spheres, triangles, materials, lights, BVH (RtDevScene offsets)
   // per-render workspaces
-  DevBuf aa, cloud, counters, queues, qcount, acc, fb, aux_rgb, aux_id, aux_t, suplist, trace_ws, sort_tmp, hard;
+  DevBuf aa, cloud, counters, fb, aux_rgb, aux_id, aux_t, suplist;
+  // What ONE frame with secondary rays owns while it is in flight: ray queues, sort workspace, hard-pair queue, level
+  // counters (+ their pinned read-back), pixel accumulator.  Two sets, so that two such frames can be in flight (the
+  // second set is only allocated when a frame is enqueued while the one before it is still running).
+  struct StreamWs {
+    DevBuf queues, trace_ws, hard, qcount, acc;
+    size_t acc_pixels = 0;            // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
+    uint32_t* cnt_host = nullptr;     // pinned: asynchronous read-back of the counters
+    hipEvent_t cnt_ev = nullptr;
+    bool cnt_pending = false, cnt_host_valid = false;
+    uint32_t cnt_host_levels = 0;
+    void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
+    uint32_t sort_hist_buckets = 0;
+  } ws[2];
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank, order the list was built for
   // RT_TILE_ORDER_COST: measured cost per super-tile (window-relative index) for cost_key = frame shape + what a ray costs
@@ -75,20 +88,13 @@ struct rt_scene {
   std::vector<uint32_t> cost_host;
   uint32_t cost_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool cost_valid = false, cost_wanted = false;
-  size_t acc_pixels = 0;  // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
-  // ray streaming (frames with secondary rays): sizes and device-side counters, see render_frame_impl
+  // ray streaming (frames with secondary rays): sizes shared by both workspace sets, see render_frame_impl
   uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // rays per queue, pairs, primary work items per batch
   StreamKey stream_key{};
   bool stream_verified = false;  // a frame of this key ran without dropping a ray or a pair
   uint32_t est[160] = {0};       // the counters of the last complete frame of this key (grids of the next one)
   bool est_valid = false;
-  uint32_t* cnt_host = nullptr;  // pinned: asynchronous read-back of the counters
-  hipEvent_t cnt_ev = nullptr;
-  bool cnt_pending = false, cnt_host_valid = false;
-  uint32_t cnt_host_levels = 0;
   uint32_t sort_bits_wanted = 0;    // rt_tuning.sort_bits of the current frame (0 = default)
-  void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
-  uint32_t sort_hist_buckets = 0;
   uint32_t tables_version = 0;      // bumped whenever a parameter table (AA samples, light clouds, flags, tile list) is uploaded
   float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)
@@ -108,13 +114,17 @@ struct rt_scene {
   float flags_key[8] = {-1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // beam_delta, eps, cloud centre: what the flags were built for
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
   // Frames in flight.  Consecutive frames may be enqueued on different streams so that the head of one overlaps the
-  // drain of the other (a launch cannot end before its longest wavefront does).  What a frame without secondary rays
-  // owns is its counter block: two blocks, used alternately, each guarded by the event recorded behind the frame that
-  // used it last.  Frames with secondary rays own the queues and the accumulator and wait for everything before them.
+  // drain of the other (a launch cannot end before its longest wavefront does).  A frame owns one of two SLOTS -- a
+  // counter block and, with secondary rays, a workspace set (ws[]) -- guarded by the event recorded behind the frame that
+  // used the slot last.  A frame takes a slot whose last frame has finished if there is one (a host that renders frame by
+  // frame only ever uses slot 0), else the one used longest ago.
   hipEvent_t frame_ev[2] = {nullptr, nullptr};
   bool frame_pending[2] = {false, false};
+  uint32_t frame_seq[2] = {0, 0};
   uint32_t frame_no = 0;
   int cur_block = 0, last_block = 0;
+  int cur_ws = 0;                  // workspace set of the frame being enqueued (normally its slot)
+  int ws_last_block[2] = {0, 1};   // the slot of the frame that used each workspace set last
   // which fast paths the last frame did NOT take (rt_stats.notes)
   uint32_t notes = 0;
   size_t queue_bytes = 0;  // ray queues + hard-pair queue + sort workspace of the last frame with secondary rays
