@@ -241,7 +241,7 @@ def main():
     ap.add_argument("--no-boundary-costs", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default run (config 3, one GPU): skip the short timings of configs 4 and 5 appended as `other_workloads`")
-    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames in flight (streams used alternately).  0 = 2: the head of a frame fills the CUs the drain of the one "
                          "before leaves idle (frames with secondary rays: every ray-tree level is a launch with a drain of its own)")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],

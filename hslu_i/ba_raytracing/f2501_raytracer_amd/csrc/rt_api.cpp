@@ -377,7 +377,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     put(&s->dev.off_lights, l.data(), l.size() * 4);
   }
-  if ((rc = s->counters.ensure(2 * RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
+  if ((rc = s->counters.ensure(RT_SLOTS * RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
 
   if (blob.size() >= (size_t)1 << 32) return bail(fail(RT_ERR_UNSUPPORTED, "scene data exceeds 4 GiB"));
   if ((rc = upload(s->blob, blob.data(), blob.size())) != RT_OK) return bail(rc);
@@ -458,7 +458,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     if (!s->tables_ev) HIP_TRY(hipEventCreateWithFlags(&s->tables_ev, hipEventDisableTiming));
     // (also covers the host staging vectors below: the previous asynchronous upload has read them by now)
     if (s->tables_pending) HIP_TRY(hipStreamSynchronize(s->tables_stream));
-    for (int b = 0; b < 2; b++)  // every frame still in flight (on whatever stream) reads the old tables
+    for (int b = 0; b < RT_SLOTS; b++)  // every frame still in flight (on whatever stream) reads the old tables
       if (s->frame_pending[b]) HIP_TRY(hipEventSynchronize(s->frame_ev[b]));
     uploaded = true;
     s->tables_version++;
@@ -600,11 +600,14 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   {
     // this frame's slot (counter block + workspace set): one whose last frame has finished if there is one, else the one
     // used longest ago -- whose frame this stream then waits for
-    for (int b = 0; b < 2; b++) {
+    int blk = -1, oldest = 0;
+    for (int b = 0; b < RT_SLOTS; b++) {
       if (!s->frame_ev[b]) HIP_TRY(hipEventCreateWithFlags(&s->frame_ev[b], hipEventDisableTiming));
       if (s->frame_pending[b] && hipEventQuery(s->frame_ev[b]) == hipSuccess) s->frame_pending[b] = false;
+      if (blk < 0 && !s->frame_pending[b]) blk = b;
+      if (s->frame_seq[b] < s->frame_seq[oldest]) oldest = b;
     }
-    int blk = !s->frame_pending[0] ? 0 : (!s->frame_pending[1] ? 1 : (s->frame_seq[0] <= s->frame_seq[1] ? 0 : 1));
+    if (blk < 0) blk = oldest;
     if (s->frame_pending[blk]) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[blk], 0));
     s->frame_seq[blk] = ++s->frame_no;
     s->cur_block = blk;
@@ -737,7 +740,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
   // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
   int wsi = s->cur_block;
-  if (wsi == 1 && !s->ws[1].queues.p && s->ws[0].queues.p) {
+  if (wsi > 0 && !s->ws[wsi].queues.p && s->ws[0].queues.p) {
     size_t free_b = 0, total_b = 0;
     const size_t one_set = s->ws[0].queues.cap + s->ws[0].trace_ws.cap + s->ws[0].hard.cap + s->ws[0].acc.cap;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * one_set) wsi = 0;

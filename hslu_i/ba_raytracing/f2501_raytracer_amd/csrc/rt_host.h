@@ -21,6 +21,9 @@ int rt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3))
                   hipGetErrorString(e_));                                                      \
   } while (0)
 
+// frames of one scene that can be in flight at once (slots: counter block + workspace set)
+#define RT_SLOTS 4
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -80,7 +83,7 @@ struct rt_scene {
     uint32_t cnt_host_levels = 0;
     void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
     uint32_t sort_hist_buckets = 0;
-  } ws[2];
+  } ws[RT_SLOTS];
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank, order the list was built for
   // RT_TILE_ORDER_COST: measured cost per super-tile (window-relative index) for cost_key = frame shape + what a ray costs
@@ -114,17 +117,17 @@ struct rt_scene {
   float flags_key[8] = {-1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // beam_delta, eps, cloud centre: what the flags were built for
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
   // Frames in flight.  Consecutive frames may be enqueued on different streams so that the head of one overlaps the
-  // drain of the other (a launch cannot end before its longest wavefront does).  A frame owns one of two SLOTS -- a
+  // drain of the other (a launch cannot end before its longest wavefront does).  A frame owns one of RT_SLOTS SLOTS -- a
   // counter block and, with secondary rays, a workspace set (ws[]) -- guarded by the event recorded behind the frame that
   // used the slot last.  A frame takes a slot whose last frame has finished if there is one (a host that renders frame by
   // frame only ever uses slot 0), else the one used longest ago.
-  hipEvent_t frame_ev[2] = {nullptr, nullptr};
-  bool frame_pending[2] = {false, false};
-  uint32_t frame_seq[2] = {0, 0};
+  hipEvent_t frame_ev[RT_SLOTS] = {};
+  bool frame_pending[RT_SLOTS] = {};
+  uint32_t frame_seq[RT_SLOTS] = {};
   uint32_t frame_no = 0;
   int cur_block = 0, last_block = 0;
   int cur_ws = 0;                  // workspace set of the frame being enqueued (normally its slot)
-  int ws_last_block[2] = {0, 1};   // the slot of the frame that used each workspace set last
+  int ws_last_block[RT_SLOTS] = {0, 1, 2, 3};  // the slot of the frame that used each workspace set last
   // which fast paths the last frame did NOT take (rt_stats.notes)
   uint32_t notes = 0;
   size_t queue_bytes = 0;  // ray queues + hard-pair queue + sort workspace of the last frame with secondary rays

@@ -28,14 +28,16 @@ ap.add_argument("workload", nargs="?", default="c3")
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--orders", default="1,2")
+ap.add_argument("--streams", default="1,2", help="numbers of streams (frames in flight) to time")
 args = ap.parse_args()
 
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 cfg, flat, _ = bench.build_workload(args.workload)
 ds = DeviceScene(flat, 0)
-fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(2)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+NS = [int(v) for v in args.streams.split(",")]
+fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(max(NS))]
+streams = [torch.cuda.Stream(device=dev) for _ in range(max(NS))]
 K = args.frames
 ref = None
 whole = {}
@@ -45,7 +47,7 @@ for n_ranks in (int(v) for v in args.ranks.split(",")):
         for rank in range(n_ranks):
             p, keep = _abi.make_params(cfg, n_ranks=n_ranks, rank=rank, tuning=dict(tile_order=order))
             res = []
-            for n_streams in (1, 2):
+            for n_streams in NS:
                 for i in range(4):  # warm-up (the first frame of a cost-ordered shape is the calibration frame)
                     _lib.check(lib.rt_render_device(ds.handle, C.byref(p), C.c_void_p(fbs[i % n_streams].data_ptr()), None,
                                                     C.c_void_p(streams[i % n_streams].cuda_stream)))
@@ -62,16 +64,16 @@ for n_ranks in (int(v) for v in args.ranks.split(",")):
                 img = fbs[0].cpu().numpy().view(np.uint32)
                 if ref is None:
                     ref = img.copy()
-                assert np.array_equal(img, ref) and np.array_equal(fbs[1].cpu().numpy().view(np.uint32), ref), "image changed"
+                assert all(np.array_equal(fb.cpu().numpy().view(np.uint32), ref) for fb in fbs[:NS[-1]]), "image changed"
             rows.append((rank, res))
         tag = {1: "row-major", 2: "cost order"}[order]
         for rank, res in rows:
-            print(f"ranks {n_ranks} rank {rank} {tag:10s}: 1 stream {res[0][0]:.3f} ms/frame, 2 streams {res[1][0]:.3f} ms/frame "
-                  f"(host enqueue {res[1][1]:.3f})")
-        slow1, slow2 = max(r[1][0][0] for r in rows), max(r[1][1][0] for r in rows)
+            print(f"ranks {n_ranks} rank {rank} {tag:10s}: " + ", ".join(f"{n} stream(s) {r[0]:.3f} ms/frame" for n, r in zip(NS, res))
+                  + f" (host enqueue {res[-1][1]:.3f})")
+        slow = [max(r[1][i][0] for r in rows) for i in range(len(NS))]
         if n_ranks == 1:
-            whole[order] = (slow1, slow2)
-        w = whole.get(order, whole.get(1, (slow1, slow2)))
-        print(f"== {n_ranks} ranks, {tag}: slowest rank {slow1:.3f} ms (1 stream) -> {w[0] / slow1:.2f}x, "
-              f"{slow2:.3f} ms (2 streams) -> {w[1] / slow2:.2f}x of the whole frame's {w[0]:.3f} / {w[1]:.3f} ms")
+            whole[order] = slow
+        w = whole.get(order, whole.get(1, slow))
+        print(f"== {n_ranks} ranks, {tag}: slowest rank " + ", ".join(f"{sl:.3f} ms ({n} stream(s)) -> {wi / sl:.2f}x" for n, sl, wi in zip(NS, slow, w))
+              + " of the whole frame's " + " / ".join(f"{wi:.3f}" for wi in w) + " ms")
 ds.close()
