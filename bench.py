@@ -198,7 +198,7 @@ def boundary_costs(cfg, flat, lib, _abi, _lib, device):
     }
 
 
-def time_workload(key, lib, _abi, _lib, DeviceScene, torch, dev, device_index, steps=8, warmup=2):
+def time_workload(key, lib, _abi, _lib, DeviceScene, torch, dev, device_index, steps=8, warmup=4):
     """ms per frame and Mray/s of another workload: `steps` frames back to back through rt_render_device on two streams
     used alternately, HBM-resident frame buffers, wall clock between two synchronisations."""
     cfg, flat, name = build_workload(key)

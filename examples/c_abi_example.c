@@ -115,6 +115,19 @@ int main(void) {
            sm.rays_primary != st.rays_primary;
     printf("rt_render_multi: 1 GPU and 3 ranks on one GPU %s rt_render (gather %.3f ms, d2h %.3f ms)\n",
            bad ? "DIFFER from" : "match", sm.gather_ms, sm.d2h_ms);
+    /* a host that renders frame after frame: two frames in flight (begin, begin, end, end) */
+    uint32_t* second = (uint32_t*)calloc((size_t)p.width * p.height, 4);
+    int t0 = -1, t1 = -1;
+    memset(multi, 0, (size_t)p.width * p.height * 4);
+    if (rt_render_multi_begin(three, 3, &p3, multi, &t0) != RT_OK || rt_render_multi_begin(three, 3, &p3, second, &t1) != RT_OK ||
+        rt_render_multi_end(t0, NULL) != RT_OK || rt_render_multi_end(t1, NULL) != RT_OK) {
+      fprintf(stderr, "rt_render_multi_begin/_end: %s\n", rt_last_error());
+      return 1;
+    }
+    const int bad2 = memcmp(multi, argb, (size_t)p.width * p.height * 4) != 0 || memcmp(second, argb, (size_t)p.width * p.height * 4) != 0;
+    printf("rt_render_multi_begin/_end: two frames in flight %s rt_render\n", bad2 ? "DIFFER from" : "match");
+    bad |= bad2;
+    free(second);
     rt_multi_release();
     rt_scene_destroy(three[1]);
     rt_scene_destroy(three[2]);

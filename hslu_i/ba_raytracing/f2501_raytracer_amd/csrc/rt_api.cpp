@@ -600,15 +600,20 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   {
     // this frame's slot (counter block + workspace set): one whose last frame has finished if there is one, else the one
     // used longest ago -- whose frame this stream then waits for
-    int blk = -1, oldest = 0;
+    // (a slot whose last frame ran on THIS stream is taken first: the stream orders the two frames anyway, and a host that
+    // runs far ahead of the GPU on two streams then holds two workspace sets, not one per slot)
+    int blk = -1, oldest = 0, same = -1;
     for (int b = 0; b < RT_SLOTS; b++) {
       if (!s->frame_ev[b]) HIP_TRY(hipEventCreateWithFlags(&s->frame_ev[b], hipEventDisableTiming));
       if (s->frame_pending[b] && hipEventQuery(s->frame_ev[b]) == hipSuccess) s->frame_pending[b] = false;
       if (blk < 0 && !s->frame_pending[b]) blk = b;
+      if (same < 0 && s->frame_seq[b] && s->frame_stream[b] == stream) same = b;
       if (s->frame_seq[b] < s->frame_seq[oldest]) oldest = b;
     }
+    if (same >= 0 && s->frame_pending[same]) blk = same;  // still running: queue up behind it on its stream
     if (blk < 0) blk = oldest;
-    if (s->frame_pending[blk]) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[blk], 0));
+    if (s->frame_pending[blk] && s->frame_stream[blk] != stream) HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[blk], 0));
+    s->frame_stream[blk] = stream;
     s->frame_seq[blk] = ++s->frame_no;
     s->cur_block = blk;
     unsigned long long* blk_p = (unsigned long long*)s->counters.p + (size_t)blk * RT_COUNTER_REPLICAS * 16;

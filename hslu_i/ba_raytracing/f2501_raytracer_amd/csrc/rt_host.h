@@ -124,6 +124,7 @@ struct rt_scene {
   hipEvent_t frame_ev[RT_SLOTS] = {};
   bool frame_pending[RT_SLOTS] = {};
   uint32_t frame_seq[RT_SLOTS] = {};
+  hipStream_t frame_stream[RT_SLOTS] = {};  // the stream the slot's last frame was enqueued on
   uint32_t frame_no = 0;
   int cur_block = 0, last_block = 0;
   int cur_ws = 0;                  // workspace set of the frame being enqueued (normally its slot)

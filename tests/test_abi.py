@@ -106,5 +106,6 @@ def test_c_example_renders_on_the_gpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rays 7680," in out.stdout and "pixels written 0 " not in out.stdout
+    assert "two frames in flight match rt_render" in out.stdout and "3 ranks on one GPU match" in out.stdout
     # the multi-GPU entry point with n_gpu = 1 and with 3 tile-partitioned ranks rehearsed on the one GPU
     assert "rt_render_multi: 1 GPU and 3 ranks on one GPU match rt_render" in out.stdout
