@@ -77,7 +77,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
     for (DevBuf* b : {&w.queues, &w.qcount, &w.acc, &w.trace_ws, &w.hard}) b->release();
   }
-  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags})
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags, &s->cell_lists})
     b->release();
   delete s;
 }
@@ -570,12 +570,26 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
         B.flag_geo = (const float4*)s->flag_geo.p;
         B.n_cells = s->n_cells;
         B.n_tri_cells = s->n_tri_cells;
+        // per-cell candidate lists, written by the same kernel: 16 bytes per cell and light (16-bit leaf slots), when the
+        // scene allows it and a quarter of the free memory holds them
+        s->cell_lists_built = false;
+        B.cell_list_out = nullptr;
+        const size_t list_bytes = (size_t)s->n_cells * s->dev.n_lights * 16u;
+        size_t free_b = 0, total_b = 0;
+        if (s->dev.n_slots <= 65533u && hipMemGetInfo(&free_b, &total_b) == hipSuccess && list_bytes <= (free_b + s->cell_lists.cap) / 4 &&
+            s->cell_lists.ensure(list_bytes + 64) == RT_OK) {
+          HIP_TRY(hipMemsetAsync(s->cell_lists.p, 0xFF, list_bytes, stream));
+          B.cell_list_out = (uint16_t*)s->cell_lists.p;
+          s->cell_lists_built = true;
+        }
         hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));
         memcpy(s->flags_key, key, sizeof(key));
       }
       P->recv_flags = (const uint16_t*)s->flags.p;
+      if (s->cell_lists_built && !p->tuning.no_cell_lists) P->cell_lists = (const uint4*)s->cell_lists.p;
     }
+    if (!P->cell_lists) s->notes |= RT_NOTE_CELL_LISTS_OFF;
   }
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;
@@ -975,9 +989,17 @@ int rt_render_device(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const 
 
 int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   if (!s || !st) return fail(RT_ERR_INVALID_ARG, "null argument");
+  return rt_collect_stats_slot(s, s->last_block, st);
+}
+
+}  // extern "C"
+
+// the ray counters of the frame that used `slot` last (the caller has waited for that frame)
+int rt_collect_stats_slot(rt_scene* s, int slot, rt_stats* st) {
+  if (!s || !st || slot < 0 || slot >= RT_SLOTS) return fail(RT_ERR_INVALID_ARG, "bad argument");
   HIP_TRY(hipSetDevice(s->device));
   unsigned long long all[RT_COUNTER_REPLICAS * 16];
-  HIP_TRY(hipMemcpy(all, (unsigned long long*)s->counters.p + (size_t)s->last_block * RT_COUNTER_REPLICAS * 16, sizeof(all), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(all, (unsigned long long*)s->counters.p + (size_t)slot * RT_COUNTER_REPLICAS * 16, sizeof(all), hipMemcpyDeviceToHost));
   unsigned long long c[16] = {0};
   for (unsigned r = 0; r < RT_COUNTER_REPLICAS; r++)
     for (unsigned i = 0; i < 16; i++) c[i] += all[r * 16 + i];
@@ -1000,6 +1022,8 @@ int rt_render_collect_stats(rt_scene* s, rt_stats* st) {
   st->queue_bytes = s->queue_bytes;
   return RT_OK;
 }
+
+extern "C" {
 
 
 int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux, rt_stats* stats) {

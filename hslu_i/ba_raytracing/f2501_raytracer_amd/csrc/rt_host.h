@@ -113,6 +113,8 @@ struct rt_scene {
   float cloud_ball[4] = {0.f, 0.f, 0.f, -1.f};  // centre offset (scene units) + radius of all cloud offsets
   // receiver flags (rt_flags_kernel): cell tables built with the scene, flags rebuilt when the beam constants change
   DevBuf flag_geo, flags;
+  DevBuf cell_lists;     // per (receiver cell, light): 8 x uint16 leaf slots surviving the cell's fat beam (rt_flags_kernel)
+  bool cell_lists_built = false;
   uint32_t n_cells = 0, n_tri_cells = 0;
   float flags_key[8] = {-1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // beam_delta, eps, cloud centre: what the flags were built for
   float cloud_ball_f[3] = {0.f, 0.f, 0.f};
@@ -141,3 +143,6 @@ struct rt_scene {
 int rt_render_device_staged(rt_scene* s, const rt_params* p, uint32_t* out_dev, const uint32_t* stage_slot,
                             uint32_t tiles_x, hipStream_t stream);
 int rt_validate_params(const rt_params* p);
+// the ray counters of the frame that used frame slot `slot` of the scene last (rt_scene::cur_block right after a frame
+// was enqueued); the caller has waited for that frame
+int rt_collect_stats_slot(rt_scene* s, int slot, rt_stats* st);

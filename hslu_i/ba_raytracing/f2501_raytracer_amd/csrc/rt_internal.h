@@ -116,6 +116,11 @@ struct RtDevParams {
   // Receiver flags, one uint16 per receiver cell: bit l = no triangle can touch a soft-shadow ray from this cell towards
   // light l, bit 8 + l = no sphere can (rt_flags_kernel; nullptr = not in use).  flag_*: inputs of that kernel.
   const uint16_t* recv_flags;
+  // Per-cell candidate lists, one uint4 (8 x 16-bit leaf slots; 0xFFFF = end, entry 0 == 0xFFFE = more than 8) per
+  // (receiver cell, light): what survives the cell's fat beam, written by rt_flags_kernel together with the flags.  The
+  // union of the lists of a wavefront's cells replaces its candidate walk (nullptr = not in use).
+  const uint4* cell_lists;
+  uint16_t* cell_list_out;
   uint16_t* flag_out;
   const float4* flag_geo;         // canonical triangles: {v1, bits(R)} {e1, bits(first cell)} {e2, 0}
   uint32_t n_cells;

@@ -731,7 +731,13 @@ struct CandList {
 struct FatBeam {
   float r;       // every point of the cell lies within r (1-norm) of the beam origin
   V3 pt[8];      // the cell's corners: a triangle's cell twice, the inner and outer corners of a sphere's
+  uint16_t* list;  // this cell's candidate list for the current light (RT_CELL_LIST_SLOTS entries, preset to 0xFFFF), or nullptr
 };
+// Per-cell candidate lists (RtDevParams::cell_lists): what survives the fat beam of a receiver cell for a light is not
+// only counted (receiver flags) but LISTED, up to RT_CELL_LIST_SLOTS leaf slots; entry 0 == RT_CELL_LIST_OVERFLOW: more.
+#define RT_CELL_LIST_SLOTS 8u
+#define RT_CELL_LIST_END 0xFFFFu
+#define RT_CELL_LIST_OVERFLOW 0xFFFEu
 enum { COLLECT_OWN = 0, COLLECT_FLAGS = 1 };
 
 // MODE: COLLECT_OWN -- a wavefront's own collection at render time; COLLECT_FLAGS -- fat beams of receiver cells (fb): no
@@ -740,7 +746,8 @@ enum { COLLECT_OWN = 0, COLLECT_FLAGS = 1 };
 template <bool CULL, int MODE = COLLECT_OWN>
 __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& sc, WaveCtx& W, bool alive, V3 p, V3 c,
                                                               const RtDevParams& P, V3 p_first, float p_spread, uint32_t cand_cap,
-                                                              const FatBeam* fb = nullptr, bool walk_tris = true) {
+                                                              const FatBeam* fb = nullptr, bool walk_tris = true,
+                                                              bool have_pre = false, uint32_t pre_reg = 0, uint32_t pre_count = 0) {
   RT_OPAQUE_S(cand_cap);
   const float delta = MODE == COLLECT_FLAGS ? P.beam_delta + fb->r : P.beam_delta;
   const float delta_e5 = MODE == COLLECT_FLAGS ? P.beam_delta_e5 + fb->r : P.beam_delta_e5;
@@ -858,8 +865,13 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
     rej |= wave_ballot(zbs + sv < 0.0f) | wave_ballot((ybs + zbs) - ad - (su + sv) - dslack - 2e-6f * ad > 0.0f);
     if (!(lanes & (open | ~rej))) return true;
     if (MODE == COLLECT_FLAGS) {
-      L.umbra |= lanes & (open | ~rej);  // cells this triangle survives for
-      return true;                        // (nothing is listed)
+      const lanemask surv = lanes & (open | ~rej);
+      L.umbra |= surv;  // cells this triangle survives for
+      if (fb->list && lane_of(surv)) {  // ... and each such cell's own list (L.reg = the lane's count)
+        if (L.reg < RT_CELL_LIST_SLOTS) fb->list[L.reg] = (uint16_t)slot;
+        L.reg++;
+      }
+      return true;  // (nothing is listed for the wavefront)
     }
     // Umbra: the triangle is opaque and EVERY sample ray of the lane hits it between origin and light -- the
     // literal test would accept it for each j (u_j, v_j >= 0, u_j + v_j < 1, EPS < t_j <= tmax_j, |det_j| > EPS,
@@ -995,7 +1007,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
             L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
             L.count++;
           }
-          if ((L.umbra & grp) == grp) return;  // every lane is in full shadow: nothing left to find
+          // every lane is in full shadow: nothing left to find (receiver cells: every cell has a survivor -- enough for
+          // the flags, not for the cells' lists)
+          if ((L.umbra & grp) == grp && !(MODE == COLLECT_FLAGS && fb->list)) return;
         } else if (second) {
           in1 = true;
         } else {
@@ -1019,6 +1033,23 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
       node = next;
     }
   };
+  if (MODE == COLLECT_OWN && have_pre) {
+    // The union of the lanes' per-cell lists stands for the walk: every triangle a sample ray of any lane can hit is in it
+    // (a cell's list = what survives the cell's fat beam, a superset of what survives the beam of any point of the cell).
+    // The lanes' own beams then thin it out exactly as they thin out the leaves of a walk.
+    for (uint32_t i = 0; i < pre_count; i++) {
+      const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)pre_reg, (int)i);
+      if (beam_rejects_all(slot, grp)) continue;
+      if (L.count >= cand_cap) {
+        L.count = RT_CAND_OVERFLOW;
+        return L;
+      }
+      L.reg = (lane_id == L.count) ? slot : L.reg;
+      L.count++;
+      if ((L.umbra & grp) == grp) return L;
+    }
+    return L;
+  }
   if (octant_uniform)
     walk(std::true_type{});
   else
@@ -1392,10 +1423,12 @@ __device__ __forceinline__ void hard_push(const RtDevParams& P, lanemask m, V3 p
 // ------------------------------------------------------------------------------------------------
 // trace + shade one ray per lane (wave-cooperative traversal inside); children go to the queue
 // ------------------------------------------------------------------------------------------------
-// LDS stash: [field][256 threads], one dword per lane per field.  Fields 0-10: ray state parked across the light loop;
-// STREAM kernels: 11-16 = the lane's pixel contribution as three 64-bit fixed-point sums (RT_ACC_SCALE units).
-#define RT_STASH_FIELDS 17u
-#define RT_STASH_FIX 11u
+// LDS stash: [field][256 threads], one dword per lane per field.  Fields 0-11: ray state parked across the light loop;
+// STREAM kernels: 12-17 = the lane's pixel contribution as three 64-bit fixed-point sums (RT_ACC_SCALE units).
+#define RT_STASH_FIELDS 18u
+#define RT_STASH_CELL 11u  /* receiver cell of the hit point (RT_NO_CELL: none) */
+#define RT_STASH_FIX 12u
+#define RT_NO_CELL 0xFFFFFFFFu
 #define RT_MAT_TRANS_BIT 0x80000000u  /* stash field 6: material row | this bit when the material is transmissive */
 __device__ __forceinline__ long long* stash_fix(float* stash) { return (long long*)(stash + RT_STASH_FIX * 256u); }
 // PRE: the nearest hit was found by rt_trace_kernel and is passed in (`pre`); otherwise it is traced here.
@@ -1476,7 +1509,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
   if (hit) sf = surface_of(sc, h, r.o, d);
   if (N > 1) {
     // receiver flags of the cell the hit point lies in (bit l: no triangle can shadow it for light l, bit 8 + l: no sphere)
-    uint32_t rflags = 0u;
+    uint32_t rflags = 0u, cell = RT_NO_CELL;
     if (P.recv_flags && hit && h.id >= (int)sc.n_spheres) {
       const uint32_t ro = sc.off_recv + (uint32_t)(h.id - (int)sc.n_spheres) * 48u;
       const float4 ru = vload<float4>(sc, ro), rv = vload<float4>(sc, ro + 16u);
@@ -1487,7 +1520,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       const uint32_t ci = (uint32_t)fminf(fmaxf(cu, 0.0f), Rf - 1.0f), cj = (uint32_t)fminf(fmaxf(cv, 0.0f), Rf - 1.0f);
       // (cells beyond the hypotenuse carry no flags; the cells are computed 5 % larger than they are, which covers the
       // rounding of u and v)
-      if (rr.x != 0u && ci + cj < rr.x) rflags = P.recv_flags[rr.y + ci + rr.x * cj];
+      if (rr.x != 0u && ci + cj < rr.x) cell = rr.y + ci + rr.x * cj, rflags = P.recv_flags[cell];
     } else if (P.recv_flags && hit && h.id >= 0) {
       // a sphere: the cell of the direction centre -> p in the sphere's cube map (face = largest component)
       const uint2 sr = vload<uint2>(sc, sc.off_srecv + (uint32_t)h.id * 8u);  // {Rs, first cell}
@@ -1500,9 +1533,10 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       const float inv = __builtin_amdgcn_rcpf(fmaxf(fabsf(dm), 1e-30f)), Rf = (float)sr.x;
       const uint32_t ci = (uint32_t)fminf(fmaxf((__builtin_fmaf(du, inv, 1.0f)) * 0.5f * Rf, 0.0f), Rf - 1.0f);
       const uint32_t cj = (uint32_t)fminf(fmaxf((__builtin_fmaf(dv, inv, 1.0f)) * 0.5f * Rf, 0.0f), Rf - 1.0f);
-      if (sr.x != 0u) rflags = P.recv_flags[sr.y + (face * sr.x + cj) * sr.x + ci];
+      if (sr.x != 0u) cell = sr.y + (face * sr.x + cj) * sr.x + ci, rflags = P.recv_flags[cell];
     }
     stash[threadIdx.x + 10 * 256] = __uint_as_float(rflags);
+    stash[threadIdx.x + RT_STASH_CELL * 256] = __uint_as_float(cell);
   }
   const Mat m_lit = load_mat(sc, sf.mat);
   // the material row is simply read again after the loop (L2)
@@ -1568,6 +1602,9 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
     cand.count = RT_CAND_OVERFLOW;
     cand.spheres = 0xFFFFFFFFu;
     cand.umbra = 0ull;
+#if RT_PROFILE == 4
+    uint32_t prof_walked = 0, prof_listed = 0, prof_pre = 0;
+#endif
     if ((RT_SKIP & 4) && N > 1) {  // removal ablation: no candidate collection either
       cand.count = 0;
       cand.spheres = 0;
@@ -1582,8 +1619,47 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
         walk_tris = (use_m & ~wave_ballot(rf & 1u)) != 0ull;
         test_spheres = walk_tris || (use_m & ~wave_ballot((rf >> 8) & 1u)) != 0ull;
       }
+      // Per-cell candidate lists: when every lane in use sits in a receiver cell whose list for this light is complete,
+      // their union replaces the BVH walk (typically one to three distinct cells per wavefront: lanes of one cell share a list).
+      uint32_t pre_reg = 0, pre_count = 0;  // lane i of pre_reg = i-th slot of the union
+      bool have_pre = false;
+      if (!CULL && P.cell_lists && walk_tris) {
+        uint32_t tix = threadIdx.x;
+        RT_OPAQUE(tix);
+        const uint32_t cidx = __float_as_uint(stash[RT_STASH_CELL * 256u + tix]);
+        uint4 lst = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (use && cidx != RT_NO_CELL) lst = P.cell_lists[(size_t)cidx * sc.n_lights + l];
+        const lanemask unusable = use_m & (wave_ballot(cidx == RT_NO_CELL) | wave_ballot((lst.x & 0xFFFFu) == RT_CELL_LIST_OVERFLOW));
+        if (!unusable) {
+          have_pre = true;
+          const uint32_t lane_id = threadIdx.x & 63u;
+          for (lanemask todo = use_m & ~wave_ballot((lst.x & 0xFFFFu) == RT_CELL_LIST_END); todo;) {
+            const int fl = __ffsll((long long)todo) - 1;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cidx, fl);
+            auto add_slot = [&](uint32_t slot) {  // (uniform)
+              if (slot >= RT_CELL_LIST_OVERFLOW) return;  // end marker
+              const lanemask filled = pre_count >= 64u ? ~0ull : ((1ull << pre_count) - 1ull);
+              if (wave_ballot(pre_reg == slot) & filled) return;  // another cell listed it already
+              pre_reg = (lane_id == pre_count) ? slot : pre_reg;
+              pre_count++;
+            };
+            auto add_pair = [&](uint32_t v) {
+              const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)v, fl);
+              add_slot(w & 0xFFFFu);
+              add_slot(w >> 16);
+            };
+            add_pair(lst.x), add_pair(lst.y), add_pair(lst.z), add_pair(lst.w);
+            todo &= ~wave_ballot(cidx == c);
+          }
+          if (pre_count > 64u) have_pre = false;  // (more than a VGPR's worth of lanes: walk)
+        }
+      }
+#if RT_PROFILE == 4
+      prof_walked = (walk_tris && !have_pre) ? 1u : 0u, prof_listed = have_pre ? 1u : 0u, prof_pre = have_pre ? pre_count : 0u;
+#endif
       if (test_spheres) {
-        cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P, p_first, p_spread, P.cand_cap, nullptr, walk_tris);
+        cand = collect_light_candidates<CULL>(sc, W, use, sf.p, centre, P, p_first, p_spread, P.cand_cap, nullptr, walk_tris,
+                                              have_pre, pre_reg, pre_count);
       } else {
         cand.count = 0;  // every lane's cell is clear of triangles and spheres for this light: nothing to test
         cand.spheres = 0;
@@ -1651,10 +1727,12 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       if (nothing) {
         W.prof[0] += 1, W.prof[1] += nl;
       } else {
-        W.prof[2] += 1, W.prof[3] += nl, W.prof[4] += needy;
-        W.prof[5] += (cand.count == RT_CAND_OVERFLOW) ? 1 : 0;
+        W.prof[2] += 1, W.prof[3] += nl;
+        (void)needy;
       }
-      W.prof[6] += (uint32_t)__popcll(hit_m);
+      W.prof[4] += prof_walked;   // sets whose candidates came from a BVH walk
+      W.prof[5] += prof_listed;   // ... from the union of per-cell lists
+      W.prof[6] += prof_pre;      // slots in those unions (before the lanes' own beam tests)
     }
 #endif
 #if RT_PROFILE == 3
@@ -2553,7 +2631,10 @@ __global__ __launch_bounds__(256) void rt_flags_kernel(RtDevScene sc, RtDevParam
   for (uint32_t l = 0; l < sc.n_lights && l < 8u; l++) {
     const float4 L0 = sload<float4>(sc, sc.off_lights + l * 32u);
     const V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
+    // (the cell's candidate list for this light: RT_CELL_LIST_SLOTS 16-bit leaf slots, preset to 0xFFFF by the host)
+    fb.list = (P.cell_list_out && have) ? P.cell_list_out + ((size_t)c * sc.n_lights + l) * RT_CELL_LIST_SLOTS : nullptr;
     const CandList cl = collect_light_candidates<false, COLLECT_FLAGS>(sc, W, active, pm, centre, P, pm, 0.0f, RT_MAX_CANDIDATES, &fb);
+    if (fb.list && active && cl.reg > RT_CELL_LIST_SLOTS) fb.list[0] = (uint16_t)RT_CELL_LIST_OVERFLOW;
     const lanemask near_m = (lanemask)cl.count | ((lanemask)cl.spheres << 32);
     if (wave_ballot(active)) {
       flags |= lane_of(cl.umbra) ? 0u : (1u << l);

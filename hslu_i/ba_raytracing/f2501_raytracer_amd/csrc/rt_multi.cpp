@@ -392,6 +392,7 @@ struct MultiFrame {  // one of the two frames of a context that can be in flight
   uint32_t* argb = nullptr;  // the caller's host buffer
   rt_params params{};
   std::vector<rt_scene*> scenes;
+  std::vector<int> slots;  // the frame slot each scene rendered this frame in (its counters)
   std::chrono::steady_clock::time_point t_begin;
   uint32_t generation = 0;
 };
@@ -531,9 +532,11 @@ int multi_begin_locked(rt_scene* const* per_gpu, int n_gpu, const rt_params* par
     if ((rc = m->comm[i]->frame_open(per_gpu[i], params, &ps[i], i == 0 ? (uint32_t*)F.fb.p : (uint32_t*)nullptr, m->stream[fi][i], fi)) != RT_OK) return rc;
   std::vector<int> rcs(n, RT_OK);
   std::vector<std::string> msgs(n);
+  F.slots.assign(n, 0);
   auto work = [&](size_t i) {
     (void)hipSetDevice(devices[i]);
     rcs[i] = m->comm[i]->frame_render(per_gpu[i], &ps[i], i == 0 ? (uint32_t*)F.fb.p : nullptr, m->stream[fi][i]);
+    F.slots[i] = per_gpu[i]->cur_block;
     if (rcs[i] != RT_OK) msgs[i] = rt_last_error();
   };
   const bool blocking = (params->flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
@@ -627,8 +630,7 @@ int multi_end_locked(int ticket, rt_stats* stats) {
       rt_stats st;
       memset(&st, 0, sizeof(st));
       int rc;
-      // (with two frames in flight the scene's counters are those of the frame enqueued last on it)
-      if ((rc = rt_render_collect_stats(F.scenes[i], &st)) != RT_OK) return rc;
+      if ((rc = rt_collect_stats_slot(F.scenes[i], F.slots[i], &st)) != RT_OK) return rc;  // (this frame's own counter block)
       stats->rays_primary += st.rays_primary;
       stats->rays_reflection += st.rays_reflection;
       stats->rays_refraction += st.rays_refraction;

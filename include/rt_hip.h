@@ -130,6 +130,11 @@ typedef struct rt_tuning {
    * Morton key of the hit point (12..24; 0 = default).  More bits = neighbouring rays in a wavefront lie closer together
    * (their soft-shadow candidate walks are shared), at 8 bytes of device memory per bucket. */
   uint32_t sort_bits;
+  /* 1: no per-cell candidate lists.  Default 0: rt_flags_kernel also LISTS, per receiver cell and light, the (up to 8)
+   * triangles that survive the cell's fat beam; a wavefront whose hit points all lie in cells with complete lists takes
+   * the union of those lists instead of walking the BVH for its soft-shadow candidates -- same candidates after the
+   * lanes' own beam tests, same image.  16 bytes per cell and light of device memory. */
+  uint32_t no_cell_lists;
 } rt_tuning;
 #define RT_TILE_ORDER_DEFAULT 0u
 #define RT_TILE_ORDER_ROW_MAJOR 1u
@@ -234,6 +239,7 @@ typedef struct rt_stats {
 #define RT_NOTE_RECV_FLAGS_OFF_SCENE 0x10u    /* no receiver cells (no triangles / degenerate scene) or no light cloud */
 #define RT_NOTE_HARD_PAIRS_OFF 0x20u          /* incoherent soft-shadow sets are traced inline (light_mult > 64, linear, cap) */
 #define RT_NOTE_FRAME_BATCHED 0x40u           /* the ray queues did not fit: the frame ran in several primary batches */
+#define RT_NOTE_CELL_LISTS_OFF 0x80u          /* no per-cell candidate lists (receiver flags off, > 65 533 leaf slots, no memory, tuning) */
 
 typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */
 
@@ -362,8 +368,7 @@ int rt_render_multi(rt_scene* const* per_gpu, int n_gpu, const rt_params* params
  * as rt_render_device does); `end` waits for that frame and copies it into the argb given to `begin` (which must stay
  * valid until then).  TWO frames may be in flight: the head of frame k+1 fills the compute units that the drain of
  * frame k leaves idle -- a rank's share of a frame is a sub-millisecond launch that cannot end before its longest
- * wavefront does.  A third `begin` before an `end` is refused (RT_ERR_INVALID_ARG).  rt_render_multi = begin + end.
- * stats->rays_* are those of the frame enqueued LAST on each GPU. */
+ * wavefront does.  A third `begin` before an `end` is refused (RT_ERR_INVALID_ARG).  rt_render_multi = begin + end. */
 int rt_render_multi_begin(rt_scene* const* per_gpu, int n_gpu, const rt_params* params, uint32_t* argb, int* ticket);
 int rt_render_multi_end(int ticket, rt_stats* stats);
 /* frees the communicators / staging buffers rt_render_multi caches between calls.  The cache is deliberately NOT freed

@@ -77,10 +77,10 @@ for spec in args or ["c3"]:
         # wave_ray_lanes = prof[6], nearest_nodes = prof[0], nearest_tris = prof[1], shadow_nodes = prof[2], shadow_tris = prof[3],
         # nearest_tris_exact = prof[4], shadow_tris_exact = prof[5]
         n_no, l_no, n_tr, l_tr = st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris
-        needy, n_ov, hits = st.wave_nearest_tris_exact, st.wave_shadow_tris_exact, st.wave_ray_lanes
+        walked, listed, pre = st.wave_nearest_tris_exact, st.wave_shadow_tris_exact, st.wave_ray_lanes
         print(f"{'':28s} sets with nothing to test: {n_no} ({l_no/max(1,n_no):.1f} lanes each) | sets traced: {n_tr} "
-              f"({l_tr/max(1,n_tr):.1f} lanes each, {needy/max(1,n_tr):.1f} of them in cells that are not clear; {n_ov} overflowed) | "
-              f"lane-lights in traced sets {100.0*l_tr/max(1,l_tr+l_no):.1f} %, needy {100.0*needy/max(1,l_tr+l_no):.1f} %")
+              f"({l_tr/max(1,n_tr):.1f} lanes each) | candidates by BVH walk: {walked} sets, by per-cell lists: {listed} sets "
+              f"({pre/max(1,listed):.1f} slots per union)")
     elif os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
         # make PROFILE=3 build: outcome of the candidate sets that had something to test
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
