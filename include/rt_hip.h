@@ -127,7 +127,7 @@ typedef struct rt_tuning {
    * frame shape (one calibration frame, shader-clock sums per super-tile) and the list is launched heaviest first. */
   uint32_t tile_order;
   /* Secondary rays are shaded in the order of their hit points: a counting sort on the top `sort_bits` bits of the 30-bit
-   * Morton key of the hit point (12..24; 0 = default).  More bits = neighbouring rays in a wavefront lie closer together
+   * Morton key of the hit point (12..24; 0 = default: 22, 24 for frames of more than 32 Mi primary work items).  More bits = neighbouring rays in a wavefront lie closer together
    * (their soft-shadow candidate walks are shared), at 8 bytes of device memory per bucket. */
   uint32_t sort_bits;
   /* 1: no per-cell candidate lists.  Default 0: rt_flags_kernel also LISTS, per receiver cell and light, the (up to 8)
