@@ -555,12 +555,12 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
     // receiver flags: cells no triangle / sphere can shadow for a light skip the candidate walk (rt_flags_kernel)
     P->recv_flags = nullptr;
     // (why the flags are off, when they are: rt_stats.notes)
-    if (p->tuning.no_receiver_flags || P->cand_cap != 64u) s->notes |= RT_NOTE_RECV_FLAGS_OFF_TUNING;
+    if (p->tuning.no_receiver_flags || P->cand_cap == 0u) s->notes |= RT_NOTE_RECV_FLAGS_OFF_TUNING;
     if (!s->n_cells || !(P->cloud_delta > 0.0f)) s->notes |= RT_NOTE_RECV_FLAGS_OFF_SCENE;
     if (s->dev.n_lights > 8u) s->notes |= RT_NOTE_RECV_FLAGS_OFF_LIGHTS;
     if (p->traversal != RT_TRAVERSAL_BVH) s->notes |= RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL;
     if (p->flags & RT_FLAG_BACKFACE_CULLING) s->notes |= RT_NOTE_RECV_FLAGS_OFF_CULLING;
-    if (!p->tuning.no_receiver_flags && P->cand_cap == 64u && s->n_cells && s->dev.n_lights <= 8u && p->traversal == RT_TRAVERSAL_BVH &&
+    if (!p->tuning.no_receiver_flags && P->cand_cap != 0u && s->n_cells && s->dev.n_lights <= 8u && p->traversal == RT_TRAVERSAL_BVH &&
         !(p->flags & RT_FLAG_BACKFACE_CULLING) && P->cloud_delta > 0.0f) {
       const float key[8] = {P->beam_delta, p->eps_distance, P->cloud_centre[0], P->cloud_centre[1], P->cloud_centre[2], 1.f, 0.f, 0.f};
       if (memcmp(key, s->flags_key, sizeof(key)) != 0) {

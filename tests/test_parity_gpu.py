@@ -1327,3 +1327,28 @@ def test_two_frames_with_secondary_rays_in_flight():
     ds.close()
     for sp, fp in zip(streams, fbs):
         assert hip.hipStreamDestroy(sp) == 0 and hip.hipFree(fp) == 0
+
+
+def test_per_cell_candidate_lists_give_the_walks_candidates():
+    """Per-cell candidate lists (rt_flags_kernel lists what survives a receiver cell's fat beam; the union of a wavefront's
+    cells' lists replaces its BVH walk): the frame with the lists against the frame without them -- bit-equal float planes,
+    packed pixels and counters -- on the room built to stress the receiver cells (wall-sized receivers, close occluders,
+    grazing light, sliver and degenerate triangles), on random soups, and on semesterbild; rt_stats.notes says when they
+    are off."""
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows"], width_override=320, height_override=256,
+                                     n_cloud_sets=32, cloud_seed=2)
+    cases = [(cfg, room_scene(2, cfg), None)]
+    cfg_r = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160, height_override=128,
+                                       n_cloud_sets=16, depth_override=3, cloud_seed=4)
+    cases.append((cfg_r, random_scene(4, n_spheres=8, n_tris=900, n_lights=3, cfg=cfg_r), None))
+    cfg_s = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"], n_cloud_sets=64)
+    cases.append((cfg_s, scenes.semesterbild(cfg_s, "text").flatten(), (380, 330, 420, 300)))
+    for c, flat, win in cases:
+        a0, p0, s0 = gpu_render(c, flat, win)
+        a1, p1, s1 = gpu_render(c, flat, win, no_cell_lists=1)
+        assert not s0["notes"] & _abi.RT_NOTE_CELL_LISTS_OFF and s1["notes"] & _abi.RT_NOTE_CELL_LISTS_OFF
+        assert np.array_equal(a0, a1) and np.array_equal(p0["rgb"].view(np.uint32), p1["rgb"].view(np.uint32))
+        assert np.array_equal(p0["hit_id"], p1["hit_id"])
+        for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
+            assert s0[k] == s1[k], k
+        assert (a0 != 0).any()
