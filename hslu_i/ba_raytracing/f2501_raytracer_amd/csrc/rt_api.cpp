@@ -18,6 +18,8 @@
 
 #include "rt_host.h"
 
+static void trace_point(hipStream_t stream, const char* what, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0);  // RT_TRACE_LAUNCHES
+
 thread_local std::string g_err;
 
 int rt_fail(int code, const char* fmt, ...) {
@@ -584,6 +586,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
         }
         hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(stream, "rt_flags_kernel: cells, lights, lists", s->n_cells, s->dev.n_lights, s->cell_lists_built ? 1u : 0u);
         memcpy(s->flags_key, key, sizeof(key));
       }
       P->recv_flags = (const uint16_t*)s->flags.p;
@@ -716,6 +719,24 @@ static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;  // hard ceiling; the r
 #define RT_CNT_HITS(levels, k) ((levels) + 5u + (k))  // rays of level k that hit something
 #define RT_CNT_TOTAL(levels) (2u * (levels) + 8u)
 
+// Diagnostics: RT_TRACE_LAUNCHES=1 in the environment makes every launch of a frame wait for its kernel and report it on
+// stderr (which launch of which level does not come back, with which sizes); never set in timed runs.
+static bool trace_launches() {
+  static const bool on = [] {
+    const char* v = getenv("RT_TRACE_LAUNCHES");
+    return v && *v && *v != '0';
+  }();
+  return on;
+}
+static void trace_point(hipStream_t stream, const char* what, uint32_t a, uint32_t b, uint32_t c) {
+  if (!trace_launches()) return;
+  fprintf(stderr, "[rt_hip] %s (%u, %u, %u) launched ...", what, a, b, c);
+  fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(stream);
+  fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+  fflush(stderr);
+}
+
 static uint32_t grid_for(uint64_t items, uint32_t per_wg, uint32_t cap_wgs) {
   uint64_t w = (items + items / 16u + per_wg - 1u) / per_wg + 8u;  // a little above the guess; the loop covers the rest
   if (w > cap_wgs) w = cap_wgs;
@@ -745,6 +766,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     P.batch_first_wg = 0;
     hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, total_wgs, stream);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    trace_point(stream, "rt_primary_kernel: workgroups", total_wgs);
     return RT_OK;
   }
   int rc;
@@ -814,7 +836,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
     const size_t held = w.queues.cap + w.hard.cap + w.trace_ws.cap;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
-    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)(q * (2u * 64u + 4u) + (h ? (h + 64u) * 64u : 0u)); };
+    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)); };
     while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
       // does not fit: smaller primary batches, queues and pair buffer in proportion
       s->q_cap = std::max<uint32_t>(s->q_cap / 2u, 1u << 16);
@@ -823,11 +845,12 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       s->stream_verified = false;
     }
     s->batch_items = (s->batch_items + 255u) / 256u * 256u;
+    s->q_cap = (uint32_t)std::min<uint64_t>(((uint64_t)s->q_cap + 255u) / 256u * 256u, 0xFFFFFF00ull);  // (16-byte aligned arrays behind it)
     // (more rays per level = more rays per bucket: two more key bits for 4K-sized frames: config 5 136.2 -> 133.4 ms)
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : (items >= (32ull << 20) ? RT_SORT_BITS_DEFAULT + 2u : RT_SORT_BITS_DEFAULT);
     const uint32_t n_buckets = 1u << P.sort_bits;
     rc = w.queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
-    if (rc == RT_OK) rc = w.trace_ws.ensure((size_t)s->q_cap * 4 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+    if (rc == RT_OK) rc = w.trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
     if (rc == RT_OK && hard) rc = w.hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
       s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
@@ -841,8 +864,9 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       w.acc_pixels = npix;
     }
     uint32_t* ws = (uint32_t*)w.trace_ws.p;
-    P.sh_idx = ws;
-    P.sort_hist = ws + s->q_cap;
+    P.sort_slot = (uint2*)ws;  // (8-byte aligned: first)
+    P.sh_idx = ws + (size_t)2 * s->q_cap;
+    P.sort_hist = P.sh_idx + s->q_cap;
     P.sort_offs = P.sort_hist + n_buckets;
     P.sort_tile = P.sort_offs + n_buckets;
     if (w.sort_hist_clean != (void*)P.sort_hist || w.sort_hist_buckets != n_buckets) {
@@ -875,6 +899,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       const uint32_t g = guess ? grid_for(s->est[RT_CNT_HARD_STAT(levels) + 1u], pairs_per_wg, hard_cap_wgs) : std::min(hard_cap_wgs, 16384u);
       hipError_t e = (hipError_t)rt_launch_hard(s->dev, P, g, stream);
       if (e != hipSuccess) return fail(RT_ERR_HIP, "hard-pair launch failed: %s", hipGetErrorString(e));
+      trace_point(stream, "rt_hard_kernel: workgroups, pair capacity", g, s->hard_cap);
       HIP_TRY(hipMemsetAsync(P.hard_count, 0, 4, stream));  // (stream ordered: behind the kernel that read it)
       return RT_OK;
     };
@@ -888,6 +913,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       P.q_out_count = counts + RT_CNT_LEVEL(1);
       hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, nw, stream);
       if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      trace_point(stream, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
       for (uint32_t k = 1; k <= levels; k++) {
         if ((rc = run_hard()) != RT_OK) return rc;  // the pairs the launch before deferred
         P.q_in = q[(k - 1u) & 1u];
@@ -904,15 +930,19 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         const uint32_t g_hits = guess ? grid_for(s->est[RT_CNT_HITS(levels, k)], 256u, cap_wgs) : cap_wgs;
         e = (hipError_t)rt_launch_trace(s->dev, P, g_rays, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
+        trace_point(stream, "rt_trace_kernel: level, workgroups", k, g_rays);
         e = (hipError_t)rt_launch_sort(P, g_rays, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
+        trace_point(stream, "sort kernels: level, buckets", k, n_buckets);
         e = (hipError_t)rt_launch_shade(s->dev, P, g_hits, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+        trace_point(stream, "rt_shade_kernel: level, workgroups", k, g_hits);
       }
       if ((rc = run_hard()) != RT_OK) return rc;  // pairs deferred by the last level's shading
     }
     hipError_t e = (hipError_t)rt_launch_resolve(P, stream);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
+    trace_point(stream, "rt_resolve_kernel: attempt", (uint32_t)attempt);
 
     // ---- the frame's counters come back asynchronously (grids of the next frame); an unverified shape waits for them
     if (w.cnt_pending && (!s->stream_verified || blocking)) {  // (an older read-back still owns the pinned buffer)

@@ -170,6 +170,7 @@ struct RtDevParams {
   uint32_t* sort_tile;    // [(1 << sort_bits) / RT_SORT_TILE]: tile -> first sorted position
   uint32_t* sort_hits;    // device scalar: rays of this level that hit something (= rays rt_shade_kernel shades)
   uint32_t* sh_idx;       // [q_capacity] sorted position -> ray index
+  uint2* sort_slot;       // [q_capacity] ray -> {bucket or 0xFFFFFFFF for a miss, rank inside the bucket}
   uint32_t sort_bits;
   uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
   // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;

@@ -60,6 +60,23 @@
 // and/or/andn2; lane_of() turns a mask back into a per-lane predicate where a select needs one (free).
 typedef unsigned long long lanemask;
 #define lane_of(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+
+// Wave-uniform values kept in the LANES of one VGPR (walk stacks, candidate lists): entry `lane` := value.  v_writelane_b32
+// ignores EXEC, as v_readlane_b32 does: the entry is stored whether or not lane `lane` is enabled where the compiler placed
+// the code.  (A select on the lane id is not: rt_flags_kernel's last wavefront ran its walks with EXEC = the lanes that
+// own a cell -- one lane for a scene of 64 k + 1 cells -- and lost every push to a higher lane: a walk that popped stale
+// entries for ever, found by the fuzz sweep, seed 61.)
+#ifndef RT_LANE_PUT_SELECT
+#define RT_LANE_PUT_SELECT 0
+#endif
+// (clang has no __builtin_amdgcn_writelane; the intrinsic is declared the way the HIP device headers declare theirs)
+extern "C" __device__ int rt_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
+__device__ __forceinline__ void lane_put(uint32_t& reg, uint32_t lane, uint32_t value, uint32_t lane_id) {
+  if (RT_LANE_PUT_SELECT)
+    reg = (lane_id == lane) ? value : reg;
+  else
+    reg = (uint32_t)rt_llvm_writelane((int)value, (int)lane, (int)reg);
+}
 // Diagnostic build (make PROFILE=1 -> librt_hip_prof.so): wave-level shader-clock timers (s_memtime) around
 // the regions of the light loop; their sums replace the work counters in rt_stats (tools/perf_ab.py --prof).
 #ifndef RT_PROFILE
@@ -674,7 +691,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
           const lanemask pref1 = wave_ballot(tn1 < tn0) & both;
           first1 = 2 * __popcll(pref1) > __popcll(both);
         }
-        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;  // push: lane `sp` of the stack register
+        lane_put(stk, sp, first1 ? nd.c0 : nd.c1, lane_id);  // push: lane `sp` of the stack register
         sp++;
         next = first1 ? nd.c1 : nd.c0;
       } else if (in0) {
@@ -1004,7 +1021,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
           }
           for (uint32_t k = 0; k < nn; k++) {
             if (beam_rejects_all(cc + k, b)) continue;  // no sample of any lane can hit it
-            L.reg = (lane_id == L.count) ? (cc + k) : L.reg;
+            lane_put(L.reg, L.count, cc + k, lane_id);
             L.count++;
           }
           // every lane is in full shadow: nothing left to find (receiver cells: every cell has a survivor -- enough for
@@ -1017,7 +1034,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
         }
       }
       if (in0 && in1) {
-        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
+        lane_put(stk, sp, first1 ? nd.c0 : nd.c1, lane_id);
         sp++;
         next = first1 ? nd.c1 : nd.c0;
       } else if (in0) {
@@ -1044,7 +1061,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
         L.count = RT_CAND_OVERFLOW;
         return L;
       }
-      L.reg = (lane_id == L.count) ? slot : L.reg;
+      lane_put(L.reg, L.count, slot, lane_id);
       L.count++;
       if ((L.umbra & grp) == grp) return L;
     }
@@ -1181,7 +1198,7 @@ __device__ __forceinline__ Shadow shadow_ray(const RtDevScene& sc, const RtDevPa
         const unsigned long long both = b0 & b1;
         const unsigned long long pref1 = wave_ballot(tn1 < tn0) & both;
         const bool first1 = 2 * __popcll(pref1) > __popcll(both);
-        stk = (lane_id == sp) ? (first1 ? nd.c0 : nd.c1) : stk;
+        lane_put(stk, sp, first1 ? nd.c0 : nd.c1, lane_id);
         sp++;
         next = first1 ? nd.c1 : nd.c0;
       } else if (in0) {
@@ -1640,7 +1657,7 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
               if (slot >= RT_CELL_LIST_OVERFLOW) return;  // end marker
               const lanemask filled = pre_count >= 64u ? ~0ull : ((1ull << pre_count) - 1ull);
               if (wave_ballot(pre_reg == slot) & filled) return;  // another cell listed it already
-              pre_reg = (lane_id == pre_count) ? slot : pre_reg;
+              lane_put(pre_reg, pre_count, slot, lane_id);
               pre_count++;
             };
             auto add_pair = [&](uint32_t v) {
@@ -2327,8 +2344,11 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
       if (lane_of(same)) rank = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
       todo &= ~same;
     }
-    if (have)
+    if (have) {
       P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u] = make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(key), __uint_as_float(rank));
+      // what rt_sort_place_kernel needs, 8 coalesced bytes per ray (it would pull the 64-byte record for them otherwise)
+      P.sort_slot[i] = make_uint2(hit ? bucket : 0xFFFFFFFFu, rank);
+    }
   }
   wave_flush(wv, P, 0ull, lds_cnt);
 }

@@ -404,7 +404,6 @@ struct MultiCtx {
   std::vector<ncclComm_t> nccl;        // ncclCommInitAll
   uint32_t transport = RT_TRANSPORT_NONE;
   MultiFrame frame[2];
-  uint32_t next = 0;
   hipEvent_t peer_done = nullptr;
   int id = 0;  // part of a frame's ticket
 };
@@ -504,7 +503,7 @@ int multi_begin_locked(rt_scene* const* per_gpu, int n_gpu, const rt_params* par
   MultiCtx* m = nullptr;
   int rc = get_ctx(devices, params->tuning.multi_force_rccl != 0, &m);
   if (rc != RT_OK) return rc;
-  const int fi = (int)(m->next & 1u);
+  const int fi = !m->frame[0].open ? 0 : 1;  // a free frame slot
   MultiFrame& F = m->frame[fi];
   if (F.open) return fail(RT_ERR_INVALID_ARG, "two frames are already in flight on these GPUs: call rt_render_multi_end first");
   const size_t n = (size_t)n_gpu;
@@ -591,7 +590,6 @@ int multi_begin_locked(rt_scene* const* per_gpu, int n_gpu, const rt_params* par
   F.params = *params;
   F.scenes.assign(per_gpu, per_gpu + n);
   F.generation++;
-  m->next++;
   // ticket: which context, which frame slot, which use of it
   static_assert(sizeof(int) >= 4, "ticket");
   *ticket = (m->id << 8) | (int)((F.generation & 0x7Fu) << 1) | fi;

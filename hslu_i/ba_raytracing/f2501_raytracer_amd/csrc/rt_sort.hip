@@ -4,15 +4,16 @@
 // that hit neighbouring surface points share one soft-shadow candidate walk).
 //
 //   rt_trace_kernel        (rt_kernels.hip) bucket = top bits of the Morton key of the hit point; rank inside the bucket from
-//                          the histogram (one atomic per wavefront and distinct bucket); both stored in the ray's record
+//                          the histogram (one atomic per wavefront and distinct bucket); both stored in sort_slot[ray]
 //   rt_sort_tiles_kernel   one workgroup per RT_SORT_TILE buckets: exclusive prefix inside the tile, tile total, clears the
 //                          histogram for the next level (coalesced 16-byte accesses, 1 MiB for 2^18 buckets)
 //   rt_sort_bases_kernel   one workgroup: exclusive prefix over the tile totals; the grand total = the number of rays that
 //                          hit something = what rt_shade_kernel reads as its size
 //   rt_sort_place_kernel   ray i -> sorted position tile base + bucket offset + rank: sh_idx[position] = i
 //
-// HBM-bound integer work: per ray 16 B of its record read and 4 B written (place), 4 B read by the shade kernel; per
-// bucket 12 B.  rocPRIM's 4-pass radix sort of (key, index) pairs moved 64 B per ray and needed its size on the host.
+// HBM-bound integer work: per ray 8 B written (trace), 8 B read and 4 B written (place), 4 B read by the shade kernel; per
+// bucket 12 B.  (Round 3 first kept bucket and rank in the ray's 64-byte record: the place kernel then fetched 2.6 GB per
+// frame of config 4 for 0.3 GB of information.)  rocPRIM's 4-pass radix sort of (key, index) pairs moved 64 B per ray and needed its size on the host.
 #include <hip/hip_runtime.h>
 
 #include "rt_internal.h"
@@ -95,10 +96,9 @@ __global__ __launch_bounds__(256) void rt_sort_place_kernel(RtDevParams P) {
   uint32_t n = *(const uint32_t*)P.q_in_count;
   n = n < P.q_capacity ? n : P.q_capacity;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const float4 q3 = P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u];  // {t, hit id, Morton key, rank}
-    if (__float_as_int(q3.y) < 0) continue;                      // a miss: not shaded
-    const uint32_t b = __float_as_uint(q3.z) >> (30u - P.sort_bits);
-    P.sh_idx[P.sort_tile[b / RT_SORT_TILE] + P.sort_offs[b] + __float_as_uint(q3.w)] = i;
+    const uint2 br = P.sort_slot[i];  // {bucket (all ones: a miss, not shaded), rank inside the bucket}
+    if (br.x == 0xFFFFFFFFu) continue;
+    P.sh_idx[P.sort_tile[br.x / RT_SORT_TILE] + P.sort_offs[br.x] + br.y] = i;
   }
 }
 

@@ -1286,6 +1286,19 @@ def test_queues_that_must_grow_render_the_frame_again_with_clean_counters(seed):
     compare(cfg, flat, ((11 * seed) % 96, (5 * seed) % 80, 64, 48))
 
 
+@pytest.mark.timeout(300)
+def test_receiver_cell_count_of_64k_plus_1_last_wavefront_owns_one_cell():
+    """Fuzz seed 61: 4 520 129 receiver cells = 64 k + 1, so the last wavefront of rt_flags_kernel owns ONE cell, and the
+    compiler runs that wavefront's candidate walks with EXEC = that one lane.  The walk's stack lives in the lanes of a VGPR:
+    pushed with a select on the lane id, every entry above lane 0 was dropped and the walk popped stale entries for ever
+    (a hung kernel).  Entries are written with v_writelane_b32 now, which ignores EXEC (rt_kernels.hip lane_put)."""
+    seed = 61
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160, height_override=128,
+                                     n_cloud_sets=16, depth_override=3, cloud_seed=seed)
+    flat = random_scene(seed, n_spheres=3 + seed % 12, n_tris=200 + 37 * (seed % 40), n_lights=2 + seed % 3, cfg=cfg)
+    compare(cfg, flat, ((11 * seed) % 96, (5 * seed) % 80, 64, 48))
+
+
 def test_two_frames_with_secondary_rays_in_flight():
     """Two frames with reflections / refractions in flight on two streams: each owns a workspace set (ray queues, sort
     workspace, hard-pair queue, level counters, accumulator), so the levels of one fill the compute units the drains of the

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_parity_gpu as T  # noqa: E402
 from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig  # noqa: E402
 
+sys.stdout.reconfigure(line_buffering=True)  # (a redirected log must show progress: a silent GPU job is taken for hung)
 first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, last + 1):

@@ -29,6 +29,7 @@ ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--orders", default="1,2")
 ap.add_argument("--streams", default="1,2", help="numbers of streams (frames in flight) to time")
+ap.add_argument("--tuning", default="", help="rt_tuning fields, k=v,k=v (A/B experiments)")
 args = ap.parse_args()
 
 lib = _lib.load()
@@ -36,6 +37,7 @@ dev = torch.device("cuda", 0)
 cfg, flat, _ = bench.build_workload(args.workload)
 ds = DeviceScene(flat, 0)
 NS = [int(v) for v in args.streams.split(",")]
+TUNING = {k: int(v, 0) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)}
 fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(max(NS))]
 streams = [torch.cuda.Stream(device=dev) for _ in range(max(NS))]
 K = args.frames
@@ -45,7 +47,7 @@ for n_ranks in (int(v) for v in args.ranks.split(",")):
     for order in (int(v) for v in args.orders.split(",")):
         rows = []
         for rank in range(n_ranks):
-            p, keep = _abi.make_params(cfg, n_ranks=n_ranks, rank=rank, tuning=dict(tile_order=order))
+            p, keep = _abi.make_params(cfg, n_ranks=n_ranks, rank=rank, tuning=dict(tile_order=order, **TUNING))
             res = []
             for n_streams in NS:
                 for i in range(4):  # warm-up (the first frame of a cost-ordered shape is the calibration frame)
