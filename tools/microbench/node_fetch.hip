@@ -12,6 +12,10 @@
 //   mode 4  vector loads with a wave-uniform address (4 x global_load_dwordx4 through the vector L1, node lands in VGPRs)
 //   mode 5  BVH4-shaped step from LDS (8 x ds_read_b128)
 //   mode 6  BVH4-shaped step through vector loads (8 x global_load_dwordx4, uniform address)
+//   mode 7  a 32-byte node: boxes as 12 x uint16 on a global grid (lo rounded down, hi up), children in 2 dwords:
+//           ONE s_load_dwordx8 per step, 12 v_cvt_f32 to unpack, the grid scale folded into the lanes' fma constants
+//   mode 8  s_load_dwordx8 only (no unpacking: what the fetch alone costs at half the bytes)
+//   mode 9  s_load_dwordx4 only
 // Reported: nanoseconds per step of ONE wave (latency, 1 wave per SIMD) and per step per SIMD with 6 resident waves
 // (what the other waves can hide).
 // Build: hipcc --offload-arch=gfx950 -O3 -o node_fetch node_fetch.hip ; run on the GPU box.
@@ -61,6 +65,9 @@ __global__ __launch_bounds__(256) void walk(const Node* __restrict__ nodes, uint
   uint32_t idx = (blockIdx.x * 4u + (threadIdx.x >> 6)) & mask;
   unsigned long long acc = 0;
   for (int s = 0; s < steps; s++) {
+    // the index must be KNOWN uniform for the compiler to issue scalar loads (round 3's first table had this missing: its
+    // "scalar" rows were per-lane vector loads and are withdrawn, profiles/r03_ab_experiments.md 4a)
+    if (MODE == 0 || MODE == 1 || MODE == 3 || MODE >= 7) idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
     if (MODE == 0 || MODE == 1) {
       const Node nd = uload(&nodes[idx]);
       const unsigned long long h0 = slab(nd.lo0, nd.hi0, ix, iy, iz, nx, ny, nz), h1 = slab(nd.lo1, nd.hi1, ix, iy, iz, nx, ny, nz);
@@ -83,6 +90,30 @@ __global__ __launch_bounds__(256) void walk(const Node* __restrict__ nodes, uint
       acc += h0 ^ h1;
       const uint32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_uint(a.w)), c1 = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
       idx = (h0 ? c0 : c1) & mask;
+    } else if (MODE == 7) {
+      struct Q { uint32_t w[6]; uint32_t c0, c1; };
+      const Q q = uload((const Q*)nodes + idx);
+      float lo0[3], hi0[3], lo1[3], hi1[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const uint32_t w0 = q.w[a], w1 = q.w[3 + a];
+        lo0[a] = (float)(w0 & 0xFFFFu), hi0[a] = (float)(w0 >> 16), lo1[a] = (float)(w1 & 0xFFFFu), hi1[a] = (float)(w1 >> 16);
+      }
+      const unsigned long long h0 = slab(lo0, hi0, ix, iy, iz, nx, ny, nz), h1 = slab(lo1, hi1, ix, iy, iz, nx, ny, nz);
+      acc += h0 ^ h1;
+      idx = (h0 ? q.c0 : q.c1) & mask;
+    } else if (MODE == 8) {
+      struct Q { float lo0[3]; uint32_t c0; float hi0[3]; uint32_t c1; };
+      const Q q = uload((const Q*)nodes + idx);
+      const unsigned long long h0 = slab(q.lo0, q.hi0, ix, iy, iz, nx, ny, nz), h1 = slab(q.hi0, q.lo0, ix, iy, iz, nx, ny, nz);
+      acc += h0 ^ h1;
+      idx = (h0 ? q.c0 : q.c1) & mask;
+    } else if (MODE == 9) {
+      struct Q { float lo0[3]; uint32_t c0; };
+      const Q q = uload((const Q*)nodes + idx);
+      const unsigned long long h0 = slab(q.lo0, q.lo0, ix, iy, iz, nx, ny, nz), h1 = slab(q.lo0, q.lo0, iy, ix, iz, nx, ny, nz);
+      acc += h0 ^ h1;
+      idx = (h0 ? q.c0 : q.c0 * 7u + 1u) & mask;
     } else if (MODE == 5 || MODE == 6) {
       const uint32_t i0 = __builtin_amdgcn_readfirstlane(idx), i1 = (i0 + 1u) & mask;
       const float4* p = MODE == 5 ? (const float4*)&lds[i0] : (const float4*)&nodes[i0];
@@ -149,6 +180,10 @@ int main() {
     run<4>("vector loads, uniform address, 8 MiB table", d, n_big - 1, w);
     run<5>("BVH4 step from LDS (8 x ds_read_b128)", d, n_small - 1, w);
     run<6>("BVH4 step, vector loads, 4 KiB table", d, n_small - 1, w);
+    run<7>("32-byte node: s_load x8 + 12 cvt (hit)", d, n_small - 1, w);
+    run<7>("32-byte node: s_load x8 + 12 cvt, 4 MiB table", d, n_big - 1, w);
+    run<8>("s_load x8 only (hit)", d, n_small - 1, w);
+    run<9>("s_load x4 only (hit)", d, n_small - 1, w);
   }
   hipFree(d);
   return 0;
