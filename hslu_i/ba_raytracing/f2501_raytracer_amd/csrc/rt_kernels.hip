@@ -61,11 +61,34 @@
 typedef unsigned long long lanemask;
 #define lane_of(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 
+// Streaming accesses of the ray queues (each record is written once and read twice, gigabytes per frame): non-temporal, so
+// that they do not push the wavefronts' scratch lines out of L2 (make NT=0 for the A/B)
+#ifndef RT_NT
+#define RT_NT 1
+#endif
+typedef float rt_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rt_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 stream_load4(const float4* p) {
+  if (!RT_NT) return *p;
+  const rt_f4v v = __builtin_nontemporal_load((const rt_f4v*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store4(float4* p, float4 v) {
+  if (!RT_NT) {
+    *p = v;
+    return;
+  }
+  rt_f4v w;
+  w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+  __builtin_nontemporal_store(w, (rt_f4v*)p);
+}
+
 // Wave-uniform values kept in the LANES of one VGPR (walk stacks, candidate lists): entry `lane` := value.  v_writelane_b32
 // ignores EXEC, as v_readlane_b32 does: the entry is stored whether or not lane `lane` is enabled where the compiler placed
 // the code.  (A select on the lane id is not: rt_flags_kernel's last wavefront ran its walks with EXEC = the lanes that
 // own a cell -- one lane for a scene of 64 k + 1 cells -- and lost every push to a higher lane: a walk that popped stale
-// entries for ever, found by the fuzz sweep, seed 61.)
+// entries for ever, found by the fuzz sweep, seed 61.  The cause was a per-lane pointer in the walk's early-out condition,
+// which made the whole walk a divergent loop; that condition is uniform again, and this store no longer depends on it.)
 #ifndef RT_LANE_PUT_SELECT
 #define RT_LANE_PUT_SELECT 0
 #endif
@@ -1026,7 +1049,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
           }
           // every lane is in full shadow: nothing left to find (receiver cells: every cell has a survivor -- enough for
           // the flags, not for the cells' lists)
-          if ((L.umbra & grp) == grp && !(MODE == COLLECT_FLAGS && fb->list)) return;
+          if ((L.umbra & grp) == grp && !(MODE == COLLECT_FLAGS && P.cell_list_out)) return;  // (a UNIFORM condition: fb->list is per lane)
         } else if (second) {
           in1 = true;
         } else {
@@ -1408,9 +1431,9 @@ __device__ __forceinline__ void queue_push(const RtDevParams& P, bool on, V3 o, 
     uint32_t i = base + rankl;
     if (i < P.q_capacity) {
       float4* rec = P.q_out + (size_t)i * RT_QUEUE_QUADS;  // one 64-byte record per ray (quad 3: rt_trace_kernel)
-      rec[0] = make_float4(o.x, o.y, o.z, n_start);
-      rec[1] = make_float4(d.x, d.y, d.z, __int_as_float(pack_dkm(depth, kind, mult)));
-      rec[2] = make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix));
+      stream_store4(rec + 0, make_float4(o.x, o.y, o.z, n_start));
+      stream_store4(rec + 1, make_float4(d.x, d.y, d.z, __int_as_float(pack_dkm(depth, kind, mult))));
+      stream_store4(rec + 2, make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix)));
     } else {
       atomicAdd(P.q_overflow, 1u);  // the host sizes the queues from the frame before; a drop makes it render the frame again
     }
@@ -2260,7 +2283,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_cost_kernel(RtDe
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ RayIn load_queued_ray(const RtDevParams& P, size_t j) {
   const float4* rec = P.q_in + j * RT_QUEUE_QUADS;
-  float4 a = rec[0], b = rec[1], c = rec[2];
+  float4 a = stream_load4(rec + 0), b = stream_load4(rec + 1), c = stream_load4(rec + 2);
   RayIn r;
   r.o = mk(a.x, a.y, a.z);
   r.n_start = a.w;
@@ -2345,7 +2368,7 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
       todo &= ~same;
     }
     if (have) {
-      P.q_in[(size_t)i * RT_QUEUE_QUADS + 3u] = make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(key), __uint_as_float(rank));
+      stream_store4(P.q_in + (size_t)i * RT_QUEUE_QUADS + 3u, make_float4(h.t, __int_as_float(hit ? h.id : -1), __uint_as_float(key), __uint_as_float(rank)));
       // what rt_sort_place_kernel needs, 8 coalesced bytes per ray (it would pull the 64-byte record for them otherwise)
       P.sort_slot[i] = make_uint2(hit ? bucket : 0xFFFFFFFFu, rank);
     }
@@ -2379,7 +2402,7 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
     if (have) {
       const size_t j = jr;  // i-th ray in hit-point order: one 64-byte record
       r = load_queued_ray(P, j);
-      const float4 q3 = P.q_in[j * RT_QUEUE_QUADS + 3u];
+      const float4 q3 = stream_load4(P.q_in + j * RT_QUEUE_QUADS + 3u);
       h.t = q3.x;
       h.id = __float_as_int(q3.y);
     }
