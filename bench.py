@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames in flight (streams used alternately).  0 = 2: the head of a frame fills the CUs the drain of the one "
                          "before leaves idle (frames with secondary rays: every ray-tree level is a launch with a drain of its own)")
+    ap.add_argument("--sub-frames", type=int, default=0, choices=[0, 1, 2],
+                    help="rt_tuning.sub_frames: chains a frame with secondary rays is split into.  0 = the library's choice (two while "
+                         "no other frame of the scene is running, one otherwise); profiles use 1 (chains stretch each other's launches)")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
@@ -280,7 +283,7 @@ def main():
     t_scene = time.perf_counter()
     ds = DeviceScene(flat, device=local_rank)
     scene_create_ms = (time.perf_counter() - t_scene) * 1e3
-    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank)
+    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames))
     npix = cfg.width * cfg.height
     n_fly = args.in_flight or 2
     if args.backend == "gloo" and world > 1:

@@ -27,7 +27,8 @@ class rt_bvh_tuning(C.Structure):
 class rt_tuning(C.Structure):
     _fields_ = [("shadow_candidate_cap", C.c_uint32), ("chunk_log2", C.c_uint32), ("no_aa_dedup", C.c_uint32),
                 ("no_counters", C.c_uint32), ("multi_force_rccl", C.c_uint32), ("no_receiver_flags", C.c_uint32),
-                ("tile_order", C.c_uint32), ("sort_bits", C.c_uint32), ("no_cell_lists", C.c_uint32)]
+                ("tile_order", C.c_uint32), ("sort_bits", C.c_uint32), ("no_cell_lists", C.c_uint32),
+                ("sub_frames", C.c_uint32)]
 
 
 class rt_scene_desc(C.Structure):

@@ -77,7 +77,13 @@ void rt_scene_destroy(rt_scene* s) {
   for (auto& w : s->ws) {
     if (w.cnt_ev) (void)hipEventDestroy(w.cnt_ev);
     if (w.cnt_host) (void)hipHostFree(w.cnt_host);
-    for (DevBuf* b : {&w.queues, &w.qcount, &w.acc, &w.trace_ws, &w.hard}) b->release();
+    if (w.fork_ev) (void)hipEventDestroy(w.fork_ev);
+    w.acc.release();
+    for (auto& l : w.lane) {
+      if (l.stream) (void)hipStreamSynchronize(l.stream), (void)hipStreamDestroy(l.stream);
+      if (l.done_ev) (void)hipEventDestroy(l.done_ev);
+      for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard}) b->release();
+    }
   }
   for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags, &s->cell_lists})
     b->release();
@@ -432,6 +438,7 @@ int rt_validate_params(const rt_params* p) {
     return fail(RT_ERR_INVALID_ARG, "tuning.chunk_log2 outside 10..26");
   if (p->tuning.sort_bits && (p->tuning.sort_bits < 12u || p->tuning.sort_bits > 24u))
     return fail(RT_ERR_INVALID_ARG, "tuning.sort_bits outside 12..24");
+  if (p->tuning.sub_frames > RT_LANES) return fail(RT_ERR_INVALID_ARG, "tuning.sub_frames > %u", (unsigned)RT_LANES);
   return RT_OK;
 }
 
@@ -597,6 +604,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   P->max_depth_reflection = p->max_depth_reflection;
   P->max_depth_refraction = p->max_depth_refraction;
   s->sort_bits_wanted = p->tuning.sort_bits;
+  s->lanes_wanted = p->tuning.sub_frames;
   if (p->win_w) {
     P->win_x0 = p->win_x0, P->win_y0 = p->win_y0, P->win_w = p->win_w, P->win_h = p->win_h;
   } else {
@@ -763,7 +771,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   if (!secondary) {
     P.acc = nullptr;
     P.q_out = nullptr;
-    P.batch_first_wg = 0;
+    P.batch_first_wg = 0, P.batch_stride = 1, P.batch_group_log2 = 0;
     hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, total_wgs, stream);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     trace_point(stream, "rt_primary_kernel: workgroups", total_wgs);
@@ -778,22 +786,43 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const bool hard = P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);
+  // ---- chains.  The ray tree of a frame is a chain of launches, one per level, each with a drain of its own (a launch
+  // cannot end before its longest wavefront does).  A frame that has the GPU to itself is therefore split into two
+  // interleaved halves of its primary work-group list that run as independent chains -- own queues, own counters, own
+  // stream -- and meet in the pixel accumulator: the head of one chain's launch fills the drain of the other's
+  // (rt_tuning.sub_frames; a frame alone: config 4 51.8 -> 49.5 ms, at depth 21 102.7 -> 92.2).  When the host keeps
+  // frames in flight itself the other FRAME is the better filler (42.3 ms against 43.3 with chains on top): sub_frames = 0
+  // uses two chains only while no other frame of the scene is running (and stays with one for 8 frames after the last
+  // overlap, so that a pipeline that drains now and then does not flip -- every flip re-verifies the queue sizes).
+  uint32_t lanes = s->lanes_wanted ? std::min<uint32_t>(s->lanes_wanted, RT_LANES) : RT_LANES;
+  if (!s->lanes_wanted) {
+    bool busy = false;
+    for (int b = 0; b < RT_SLOTS; b++)
+      if (b != s->cur_block && s->frame_pending[b] && hipEventQuery(s->frame_ev[b]) == hipErrorNotReady) busy = true;
+    s->calm_frames = busy ? 0u : std::min<uint32_t>(s->calm_frames + 1u, 1u << 30);
+    if (s->calm_frames < 8u) lanes = 1;
+  }
+  if (forced_chunk_log2 || items < (1ull << 16)) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
   // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
   // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
   int wsi = s->cur_block;
-  if (wsi > 0 && !s->ws[wsi].queues.p && s->ws[0].queues.p) {
+  if (wsi > 0 && !s->ws[wsi].lane[0].queues.p && s->ws[0].lane[0].queues.p) {
     size_t free_b = 0, total_b = 0;
-    const size_t one_set = s->ws[0].queues.cap + s->ws[0].trace_ws.cap + s->ws[0].hard.cap + s->ws[0].acc.cap;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * one_set) wsi = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * s->ws[0].bytes()) wsi = 0;
   }
   if (s->ws_last_block[wsi] != s->cur_block && s->frame_pending[s->ws_last_block[wsi]])
     HIP_TRY(hipStreamWaitEvent(stream, s->frame_ev[s->ws_last_block[wsi]], 0));
   s->ws_last_block[wsi] = s->cur_block;
   s->cur_ws = wsi;
   rt_scene::StreamWs& w = s->ws[wsi];
-  if ((rc = w.qcount.ensure((size_t)n_cnt * 4)) != RT_OK) return rc;
-  if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, 160 * 4, hipHostMallocDefault));
+  for (uint32_t j = 0; j < lanes; j++) {
+    if ((rc = w.lane[j].qcount.ensure((size_t)n_cnt * 4)) != RT_OK) return rc;
+    if (j && !w.lane[j].stream) HIP_TRY(hipStreamCreateWithFlags(&w.lane[j].stream, hipStreamNonBlocking));
+    if (j && !w.lane[j].done_ev) HIP_TRY(hipEventCreateWithFlags(&w.lane[j].done_ev, hipEventDisableTiming));
+  }
+  if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, RT_LANES * 160 * 4, hipHostMallocDefault));
   if (!w.cnt_ev) HIP_TRY(hipEventCreateWithFlags(&w.cnt_ev, hipEventDisableTiming));
+  if (!w.fork_ev) HIP_TRY(hipEventCreateWithFlags(&w.fork_ev, hipEventDisableTiming));
 
   // ---- the shape of this frame: what its ray counts depend on.  Same key as the last verified frame = same counts.
   StreamKey key;
@@ -805,7 +834,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   key.cloud_seed = P.cloud_seed, key.n_cloud_sets = P.n_cloud_sets, key.forced = forced_chunk_log2;
   key.tables = s->tables_version;
   memcpy(key.f, P.focus, 12), key.f[3] = P.fw, key.f[4] = P.fh, key.f[5] = P.fd, key.f[6] = P.eps_distance, key.f[7] = P.air_ior;
-  key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup;
+  key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup, key.lanes = lanes;
   if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
     s->stream_key = key;
     s->stream_verified = false;
@@ -816,27 +845,40 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   for (auto& o : s->ws)
     if (o.cnt_pending && hipEventQuery(o.cnt_ev) == hipSuccess) {
       o.cnt_pending = false;
-      if (o.cnt_host_levels == levels && o.cnt_host_valid) memcpy(s->est, o.cnt_host, n_cnt * 4), s->est_valid = true;
+      if (o.cnt_host_levels == levels && o.cnt_host_lanes == lanes && o.cnt_host_valid) memcpy(s->est, o.cnt_host, sizeof(s->est)), s->est_valid = true;
     }
 
+  // chains other than the caller's must have drained before this function returns on an error path (their work refers to
+  // the workspace set; only the caller's stream is guarded by the frame event)
+  struct Joiner {
+    rt_scene::StreamWs& w;
+    uint32_t lanes;
+    bool forked = false, joined = false;
+    ~Joiner() {
+      if (forked && !joined)
+        for (uint32_t j = 1; j < lanes; j++) (void)hipStreamSynchronize(w.lane[j].stream);
+    }
+  } joiner{w, lanes};
+
   for (int attempt = 0;; attempt++) {
-    // ---- sizes.  Unknown shape: every level fits the primary work items (children usually thin out; a scene where
-    // they multiply is caught by the verification below), pairs = 1/8 of that.  Budget: half of the free HBM.
+    // ---- sizes, per chain.  Unknown shape: every level fits the chain's primary work items (children usually thin out; a
+    // scene where they multiply is caught by the verification below), pairs = 1/8 of that.  Budget: half of the free HBM.
     if (!s->q_cap) {
       if (forced_chunk_log2) {
         s->batch_items = 1u << forced_chunk_log2;
         s->q_cap = 2u * s->batch_items;
       } else {
-        s->batch_items = (uint32_t)std::min<uint64_t>(items, 1ull << 28);
+        const uint64_t lane_items = ((uint64_t)total_wgs + lanes - 1u) / lanes * 256u;
+        s->batch_items = (uint32_t)std::min<uint64_t>(lane_items, 1ull << 28);
         s->q_cap = s->batch_items;
       }
       if (s->q_cap < (1u << 16)) s->q_cap = 1u << 16;
       s->hard_cap = hard ? std::max<uint32_t>(s->q_cap / 8u, 1u << 16) : 0u;
     }
     size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
-    const size_t held = w.queues.cap + w.hard.cap + w.trace_ws.cap;
+    const size_t held = w.bytes() - w.acc.cap;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
-    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)); };
+    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)lanes * (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)); };
     while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
       // does not fit: smaller primary batches, queues and pair buffer in proportion
       s->q_cap = std::max<uint32_t>(s->q_cap / 2u, 1u << 16);
@@ -849,9 +891,12 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     // (more rays per level = more rays per bucket: two more key bits for 4K-sized frames: config 5 136.2 -> 133.4 ms)
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : (items >= (32ull << 20) ? RT_SORT_BITS_DEFAULT + 2u : RT_SORT_BITS_DEFAULT);
     const uint32_t n_buckets = 1u << P.sort_bits;
-    rc = w.queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
-    if (rc == RT_OK) rc = w.trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
-    if (rc == RT_OK && hard) rc = w.hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
+    rc = RT_OK;
+    for (uint32_t j = 0; j < lanes && rc == RT_OK; j++) {
+      rc = w.lane[j].queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
+      if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+      if (rc == RT_OK && hard) rc = w.lane[j].hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
+    }
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
       s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
       s->batch_items = std::max<uint32_t>(s->batch_items / 2u, 1u << 10);
@@ -863,84 +908,122 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       HIP_TRY(hipMemsetAsync(w.acc.p, 0, npix * 4 * sizeof(long long), stream));
       w.acc_pixels = npix;
     }
-    uint32_t* ws = (uint32_t*)w.trace_ws.p;
-    P.sort_slot = (uint2*)ws;  // (8-byte aligned: first)
-    P.sh_idx = ws + (size_t)2 * s->q_cap;
-    P.sort_hist = P.sh_idx + s->q_cap;
-    P.sort_offs = P.sort_hist + n_buckets;
-    P.sort_tile = P.sort_offs + n_buckets;
-    if (w.sort_hist_clean != (void*)P.sort_hist || w.sort_hist_buckets != n_buckets) {
-      // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
-      HIP_TRY(hipMemsetAsync(P.sort_hist, 0, (size_t)n_buckets * 4, stream));
-      w.sort_hist_clean = (void*)P.sort_hist;
-      w.sort_hist_buckets = n_buckets;
-    }
-    s->queue_bytes = 0;
-    for (auto& o : s->ws) s->queue_bytes += o.queues.cap + o.trace_ws.cap + o.hard.cap + o.acc.cap;
     const uint32_t n_batches = (uint32_t)((items + s->batch_items - 1) / s->batch_items);
-    if (n_batches > 1) s->notes |= RT_NOTE_FRAME_BATCHED;
-
-    uint32_t* counts = (uint32_t*)w.qcount.p;
-    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_cnt * 4, stream));
-    P.acc = (long long*)w.acc.p;
-    P.q_capacity = s->q_cap;
-    P.q_overflow = counts + RT_CNT_OVERFLOW;
-    P.hard_q = hard ? (float4*)w.hard.p : nullptr;
-    P.hard_capacity = s->hard_cap;
-    P.hard_count = counts + RT_CNT_HARD(levels);
-    P.hard_stat = counts + RT_CNT_HARD_STAT(levels);
-    float4* const q[2] = {(float4*)w.queues.p, (float4*)w.queues.p + (size_t)s->q_cap * RT_QUEUE_QUADS};
+    if (n_batches > lanes) s->notes |= RT_NOTE_FRAME_BATCHED;
     const uint32_t cap_wgs = (s->q_cap + 255u) / 256u;
-    const bool guess = s->est_valid && n_batches == 1;  // grids from the previous frame's counts (else: whole capacity)
+    const bool guess = s->est_valid && n_batches == lanes;  // grids from the previous frame's counts (else: whole capacity)
     const uint32_t ppw = 64u / (P.light_mult < 2u ? 2u : P.light_mult), pairs_per_wg = 4u * (ppw ? ppw : 1u);
     const uint32_t hard_cap_wgs = hard ? (s->hard_cap + pairs_per_wg - 1u) / pairs_per_wg : 1u;
-    auto run_hard = [&]() -> int {
+
+    // ---- every chain's view of the frame: the caller's parameters with the chain's own queues and counters
+    RtDevParams Pl[RT_LANES];
+    float4* q[RT_LANES][2];
+    uint32_t* counts[RT_LANES];
+    for (uint32_t j = 0; j < lanes; j++) {
+      rt_scene::Lane& L = w.lane[j];
+      RtDevParams& Q = Pl[j];
+      Q = P;
+      uint32_t* ws = (uint32_t*)L.trace_ws.p;
+      Q.sort_slot = (uint2*)ws;  // (8-byte aligned: first)
+      Q.sh_idx = ws + (size_t)2 * s->q_cap;
+      Q.sort_hist = Q.sh_idx + s->q_cap;
+      Q.sort_offs = Q.sort_hist + n_buckets;
+      Q.sort_tile = Q.sort_offs + n_buckets;
+      if (L.sort_hist_clean != (void*)Q.sort_hist || L.sort_hist_buckets != n_buckets) {
+        // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
+        HIP_TRY(hipMemsetAsync(Q.sort_hist, 0, (size_t)n_buckets * 4, stream));
+        L.sort_hist_clean = (void*)Q.sort_hist;
+        L.sort_hist_buckets = n_buckets;
+      }
+      counts[j] = (uint32_t*)L.qcount.p;
+      HIP_TRY(hipMemsetAsync(counts[j], 0, (size_t)n_cnt * 4, stream));
+      Q.acc = (long long*)w.acc.p;
+      Q.q_capacity = s->q_cap;
+      Q.q_overflow = counts[j] + RT_CNT_OVERFLOW;
+      Q.hard_q = hard ? (float4*)L.hard.p : nullptr;
+      Q.hard_capacity = s->hard_cap;
+      Q.hard_count = counts[j] + RT_CNT_HARD(levels);
+      Q.hard_stat = counts[j] + RT_CNT_HARD_STAT(levels);
+      q[j][0] = (float4*)L.queues.p, q[j][1] = (float4*)L.queues.p + (size_t)s->q_cap * RT_QUEUE_QUADS;
+    }
+    s->queue_bytes = 0;
+    for (auto& o : s->ws) s->queue_bytes += o.bytes();
+    if (lanes > 1) {  // fork: the other chains start behind everything enqueued on the caller's stream so far
+      HIP_TRY(hipEventRecord(w.fork_ev, stream));
+      for (uint32_t j = 1; j < lanes; j++) HIP_TRY(hipStreamWaitEvent(w.lane[j].stream, w.fork_ev, 0));
+      joiner.forked = true, joiner.joined = false;
+    }
+    auto run_hard = [&](uint32_t j, hipStream_t st) -> int {
       if (!hard) return RT_OK;
-      const uint32_t g = guess ? grid_for(s->est[RT_CNT_HARD_STAT(levels) + 1u], pairs_per_wg, hard_cap_wgs) : std::min(hard_cap_wgs, 16384u);
-      hipError_t e = (hipError_t)rt_launch_hard(s->dev, P, g, stream);
+      RtDevParams& Q = Pl[j];
+      const uint32_t g = guess ? grid_for(s->est[j][RT_CNT_HARD_STAT(levels) + 1u], pairs_per_wg, hard_cap_wgs) : std::min(hard_cap_wgs, 16384u);
+      hipError_t e = (hipError_t)rt_launch_hard(s->dev, Q, g, st);
       if (e != hipSuccess) return fail(RT_ERR_HIP, "hard-pair launch failed: %s", hipGetErrorString(e));
-      trace_point(stream, "rt_hard_kernel: workgroups, pair capacity", g, s->hard_cap);
-      HIP_TRY(hipMemsetAsync(P.hard_count, 0, 4, stream));  // (stream ordered: behind the kernel that read it)
+      trace_point(st, "rt_hard_kernel: workgroups, pair capacity, chain", g, s->hard_cap, j);
+      HIP_TRY(hipMemsetAsync(Q.hard_count, 0, 4, st));  // (stream ordered: behind the kernel that read it)
       return RT_OK;
     };
     const uint32_t batch_wgs = s->batch_items / 256u;
-    for (uint32_t w0 = 0; w0 < total_wgs; w0 += batch_wgs) {
-      if (w0) HIP_TRY(hipMemsetAsync(counts + 1, 0, (size_t)(levels + 1) * 4, stream));  // the next batch's level counters
-      const uint32_t nw = std::min(total_wgs - w0, batch_wgs);
-      P.batch_first_wg = w0;
-      P.q_in = nullptr, P.q_in_count = nullptr;
-      P.q_out = q[0];
-      P.q_out_count = counts + RT_CNT_LEVEL(1);
-      hipError_t e = (hipError_t)rt_launch_primary(s->dev, P, nw, stream);
-      if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-      trace_point(stream, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
-      for (uint32_t k = 1; k <= levels; k++) {
-        if ((rc = run_hard()) != RT_OK) return rc;  // the pairs the launch before deferred
-        P.q_in = q[(k - 1u) & 1u];
-        P.q_in_count = counts + RT_CNT_LEVEL(k);
-        P.sort_hits = counts + RT_CNT_HITS(levels, k);
-        if (k < levels) {
-          P.q_out = q[k & 1u];
-          P.q_out_count = counts + RT_CNT_LEVEL(k + 1u);
-        } else {
-          P.q_out = nullptr;  // rays of the last level have depth 1: no children possible
-          P.q_out_count = nullptr;
-        }
-        const uint32_t g_rays = guess ? grid_for(s->est[RT_CNT_LEVEL(k)], 256u, cap_wgs) : cap_wgs;
-        const uint32_t g_hits = guess ? grid_for(s->est[RT_CNT_HITS(levels, k)], 256u, cap_wgs) : cap_wgs;
-        e = (hipError_t)rt_launch_trace(s->dev, P, g_rays, stream);
-        if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
-        trace_point(stream, "rt_trace_kernel: level, workgroups", k, g_rays);
-        e = (hipError_t)rt_launch_sort(P, g_rays, stream);
-        if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
-        trace_point(stream, "sort kernels: level, buckets", k, n_buckets);
-        e = (hipError_t)rt_launch_shade(s->dev, P, g_hits, stream);
-        if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
-        trace_point(stream, "rt_shade_kernel: level, workgroups", k, g_hits);
+    // One batch per chain (the rule): the chains INTERLEAVE, groups of 64 workgroups of the list alternately, so that each
+    // gets its share of the expensive regions (contiguous halves = sky and text: the sky's chain is done at once and the
+    // text's runs alone).  Frames batched for memory: contiguous batches, dealt to the chains in turn.
+    const uint32_t group_log2 = 6u, n_groups = (total_wgs + 63u) >> 6;
+    const bool interleave = lanes > 1 && n_batches == lanes;
+    uint32_t lane_batches[RT_LANES] = {0};
+    for (uint32_t b = 0, w0 = 0; interleave ? b < lanes : w0 < total_wgs; b++, w0 += batch_wgs) {
+      const uint32_t j = b % lanes;
+      RtDevParams& Q = Pl[j];
+      hipStream_t st = j ? w.lane[j].stream : stream;
+      if (lane_batches[j]++) HIP_TRY(hipMemsetAsync(counts[j] + 1, 0, (size_t)(levels + 1) * 4, st));  // the chain's next batch: its level counters
+      uint32_t nw = 0;
+      if (interleave) {
+        // groups j, j + lanes, ...; workgroups past the end of the list find no pixel and leave
+        nw = ((n_groups + lanes - 1u - j) / lanes) << group_log2;
+        Q.batch_first_wg = j << group_log2, Q.batch_stride = lanes, Q.batch_group_log2 = group_log2;
+      } else {
+        nw = std::min(total_wgs - w0, batch_wgs);
+        Q.batch_first_wg = w0, Q.batch_stride = 1, Q.batch_group_log2 = 0;
       }
-      if ((rc = run_hard()) != RT_OK) return rc;  // pairs deferred by the last level's shading
+      Q.q_in = nullptr, Q.q_in_count = nullptr;
+      Q.q_out = q[j][0];
+      Q.q_out_count = counts[j] + RT_CNT_LEVEL(1);
+      hipError_t e = (hipError_t)rt_launch_primary(s->dev, Q, nw, st);
+      if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      trace_point(st, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
+      for (uint32_t k = 1; k <= levels; k++) {
+        if ((rc = run_hard(j, st)) != RT_OK) return rc;  // the pairs the launch before deferred
+        Q.q_in = q[j][(k - 1u) & 1u];
+        Q.q_in_count = counts[j] + RT_CNT_LEVEL(k);
+        Q.sort_hits = counts[j] + RT_CNT_HITS(levels, k);
+        if (k < levels) {
+          Q.q_out = q[j][k & 1u];
+          Q.q_out_count = counts[j] + RT_CNT_LEVEL(k + 1u);
+        } else {
+          Q.q_out = nullptr;  // rays of the last level have depth 1: no children possible
+          Q.q_out_count = nullptr;
+        }
+        const uint32_t g_rays = guess ? grid_for(s->est[j][RT_CNT_LEVEL(k)], 256u, cap_wgs) : cap_wgs;
+        const uint32_t g_hits = guess ? grid_for(s->est[j][RT_CNT_HITS(levels, k)], 256u, cap_wgs) : cap_wgs;
+        e = (hipError_t)rt_launch_trace(s->dev, Q, g_rays, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_trace_kernel: level, workgroups, chain", k, g_rays, j);
+        e = (hipError_t)rt_launch_sort(Q, g_rays, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "sort kernels: level, buckets, chain", k, n_buckets, j);
+        e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_shade_kernel: level, workgroups, chain", k, g_hits, j);
+      }
+      if ((rc = run_hard(j, st)) != RT_OK) return rc;  // pairs deferred by the last level's shading
     }
-    hipError_t e = (hipError_t)rt_launch_resolve(P, stream);
+    if (lanes > 1) {  // join: the resolve needs every chain's sums
+      for (uint32_t j = 1; j < lanes; j++) {
+        HIP_TRY(hipEventRecord(w.lane[j].done_ev, w.lane[j].stream));
+        HIP_TRY(hipStreamWaitEvent(stream, w.lane[j].done_ev, 0));
+      }
+      joiner.joined = true;
+    }
+    hipError_t e = (hipError_t)rt_launch_resolve(Pl[0], stream);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "resolve launch failed: %s", hipGetErrorString(e));
     trace_point(stream, "rt_resolve_kernel: attempt", (uint32_t)attempt);
 
@@ -950,28 +1033,32 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       w.cnt_pending = false;
     }
     if (!w.cnt_pending) {
-      HIP_TRY(hipMemcpyAsync(w.cnt_host, counts, (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
+      for (uint32_t j = 0; j < lanes; j++)
+        HIP_TRY(hipMemcpyAsync(w.cnt_host + (size_t)j * 160u, counts[j], (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipEventRecord(w.cnt_ev, stream));
       w.cnt_pending = true;
       w.cnt_host_levels = levels;
-      w.cnt_host_valid = n_batches == 1;
+      w.cnt_host_lanes = lanes;
+      w.cnt_host_valid = n_batches == lanes;
     }
     if (s->stream_verified && !blocking) return RT_OK;
     HIP_TRY(hipEventSynchronize(w.cnt_ev));
     w.cnt_pending = false;
-    const uint32_t* c = w.cnt_host;
-    const uint32_t dropped = c[RT_CNT_OVERFLOW], dropped_pairs = c[RT_CNT_HARD_STAT(levels)];
+    uint32_t dropped = 0, dropped_pairs = 0, need = 0, need_pairs = 0;
+    for (uint32_t j = 0; j < lanes; j++) {
+      const uint32_t* c = w.cnt_host + (size_t)j * 160u;
+      dropped += c[RT_CNT_OVERFLOW], dropped_pairs += c[RT_CNT_HARD_STAT(levels)];
+      for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, c[RT_CNT_LEVEL(k)]);
+      need_pairs = std::max(need_pairs, c[RT_CNT_HARD_STAT(levels) + 1u]);
+    }
     if (!dropped && !dropped_pairs) {
-      if (w.cnt_host_valid) memcpy(s->est, c, n_cnt * 4), s->est_valid = true;
+      if (w.cnt_host_valid) memcpy(s->est, w.cnt_host, sizeof(s->est)), s->est_valid = true;
       s->stream_verified = true;
       return RT_OK;
     }
     // children or pairs were dropped: the counters say what the frame needed; render it again with that
     if (attempt >= 6) return fail(RT_ERR_HIP, "%u child rays / %u pair batches were dropped (queues could not be sized)", dropped, dropped_pairs);
-    uint32_t need = 0;
-    for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, c[RT_CNT_LEVEL(k)]);
-    const uint32_t need_pairs = c[RT_CNT_HARD_STAT(levels) + 1u];
-    if (n_batches == 1 && !forced_chunk_log2) {
+    if (n_batches == lanes && !forced_chunk_log2) {
       if (need > s->q_cap) s->q_cap = (uint32_t)std::min<uint64_t>((uint64_t)need + need / 16u + 256u, 0xFFFFFF00ull);
       if (need_pairs > s->hard_cap) s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)need_pairs + need_pairs / 8u + 256u, 0xFFFFFF00ull);
     } else {

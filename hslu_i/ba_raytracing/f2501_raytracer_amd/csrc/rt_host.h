@@ -23,6 +23,8 @@ int rt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3))
 
 // frames of one scene that can be in flight at once (slots: counter block + workspace set)
 #define RT_SLOTS 4
+// chains a frame with secondary rays is split into (rt_tuning.sub_frames)
+#define RT_LANES 2
 
 struct DevBuf {
   void* p = nullptr;
@@ -60,7 +62,7 @@ struct EventPair {  // destroyed on every return path
 // verified frame renders without a synchronisation
 struct StreamKey {
   uint32_t width, height, flags, aa_rays, aa_unique, light_mult, depth_refl, depth_refr, win[4], tile_size, n_ranks, rank, traversal,
-      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup;
+      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup, lanes;
   float f[8];
 };
 
@@ -74,15 +76,29 @@ struct rt_scene {
   // What ONE frame with secondary rays owns while it is in flight: ray queues, sort workspace, hard-pair queue, level
   // counters (+ their pinned read-back), pixel accumulator.  Two sets, so that two such frames can be in flight (the
   // second set is only allocated when a frame is enqueued while the one before it is still running).
-  struct StreamWs {
-    DevBuf queues, trace_ws, hard, qcount, acc;
-    size_t acc_pixels = 0;            // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
-    uint32_t* cnt_host = nullptr;     // pinned: asynchronous read-back of the counters
-    hipEvent_t cnt_ev = nullptr;
-    bool cnt_pending = false, cnt_host_valid = false;
-    uint32_t cnt_host_levels = 0;
+  // A frame's ray tree runs as RT_LANES independent CHAINS (halves of its primary work-group list), each with its own
+  // queues, sort workspace, pair queue and level counters; chain 0 on the caller's stream, the others on streams of the
+  // set (forked / joined with events).  The chains meet in the pixel accumulator.
+  struct Lane {
+    DevBuf queues, trace_ws, hard, qcount;
     void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
     uint32_t sort_hist_buckets = 0;
+    hipStream_t stream = nullptr;     // chains 1..: their own stream
+    hipEvent_t done_ev = nullptr;     // ... and the event the caller's stream waits for before the resolve
+  };
+  struct StreamWs {
+    Lane lane[RT_LANES];
+    DevBuf acc;
+    size_t acc_pixels = 0;            // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
+    uint32_t* cnt_host = nullptr;     // pinned, [RT_LANES][160]: asynchronous read-back of the chains' counters
+    hipEvent_t cnt_ev = nullptr, fork_ev = nullptr;
+    bool cnt_pending = false, cnt_host_valid = false;
+    uint32_t cnt_host_levels = 0, cnt_host_lanes = 0;
+    size_t bytes() const {
+      size_t b = acc.cap;
+      for (const Lane& l : lane) b += l.queues.cap + l.trace_ws.cap + l.hard.cap;
+      return b;
+    }
   } ws[RT_SLOTS];
   std::vector<uint32_t> sup_host;
   uint32_t sup_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // window, tile size, n_ranks, rank, order the list was built for
@@ -92,12 +108,14 @@ struct rt_scene {
   uint32_t cost_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool cost_valid = false, cost_wanted = false;
   // ray streaming (frames with secondary rays): sizes shared by both workspace sets, see render_frame_impl
-  uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // rays per queue, pairs, primary work items per batch
+  uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // per chain: rays per queue, pairs; primary work items per batch
   StreamKey stream_key{};
   bool stream_verified = false;  // a frame of this key ran without dropping a ray or a pair
-  uint32_t est[160] = {0};       // the counters of the last complete frame of this key (grids of the next one)
+  uint32_t est[RT_LANES][160] = {{0}};  // the counters of the last complete frame of this key, per chain (grids of the next one)
   bool est_valid = false;
   uint32_t sort_bits_wanted = 0;    // rt_tuning.sort_bits of the current frame (0 = default)
+  uint32_t lanes_wanted = 0;        // rt_tuning.sub_frames of the current frame (0 = default)
+  uint32_t calm_frames = 1u << 30;  // frames enqueued in a row while no other frame of the scene was running (sub_frames = 0: auto)
   uint32_t tables_version = 0;      // bumped whenever a parameter table (AA samples, light clouds, flags, tile list) is uploaded
   float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)
   // host copies of the parameter tables last uploaded (skip re-upload when unchanged)

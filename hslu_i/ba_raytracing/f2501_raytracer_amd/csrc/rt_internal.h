@@ -173,6 +173,10 @@ struct RtDevParams {
   uint2* sort_slot;       // [q_capacity] ray -> {bucket or 0xFFFFFFFF for a miss, rank inside the bucket}
   uint32_t sort_bits;
   uint32_t batch_first_wg;  // primary kernel: workgroup offset of this batch
+  // ... and its stride: launched workgroup b stands for workgroup first + ((b >> group_log2) * stride << group_log2) + (b & group mask) of
+  // the frame's list -- stride 1: a contiguous range; stride 2: every other group of 2^group_log2 workgroups (the chains of a
+  // frame with secondary rays interleave, so that each gets its share of the expensive regions)
+  uint32_t batch_stride, batch_group_log2;
   // multi-GPU: the 16x16 super-tiles (window-relative index) that contain pixels of this rank's tiles;
   // nullptr = all super-tiles of the window
   const uint32_t* sup_list;

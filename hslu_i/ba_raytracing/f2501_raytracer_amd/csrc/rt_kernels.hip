@@ -83,6 +83,12 @@ __device__ __forceinline__ void stream_store4(float4* p, float4 v) {
   __builtin_nontemporal_store(w, (rt_f4v*)p);
 }
 
+// the workgroup of the frame's list that launched workgroup b of a batch stands for (RtDevParams::batch_stride)
+__device__ __forceinline__ uint32_t rt_batch_wg(const RtDevParams& P, uint32_t b) {
+  const uint32_t gl = P.batch_group_log2;
+  return P.batch_first_wg + (((b >> gl) * P.batch_stride) << gl) + (b & ((1u << gl) - 1u));
+}
+
 // Wave-uniform values kept in the LANES of one VGPR (walk stacks, candidate lists): entry `lane` := value.  v_writelane_b32
 // ignores EXEC, as v_readlane_b32 does: the entry is stored whether or not lane `lane` is enabled where the compiler placed
 // the code.  (A select on the lane id is not: rt_flags_kernel's last wavefront ran its walks with EXEC = the lanes that
@@ -2079,7 +2085,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
       slot_used = m.slot < ppw;
     }
     const uint32_t st_x = (P.win_w + 15u) / 16u;
-    const uint32_t wg = P.batch_first_wg + blockIdx.x;
+    const uint32_t wg = rt_batch_wg(P, blockIdx.x);
     const uint32_t g = wg * ppw + m.slot;  // pixel ordinal in super-tile order
     const uint32_t sup_slot = g >> 8, in_sup = g & 255u;
     const bool lane_used = slot_used && (sup_slot < P.n_sup);
@@ -2217,7 +2223,7 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   if (COST && P.cost_map && (threadIdx.x & 63u) == 0) {
     const unsigned long long dt = __builtin_readcyclecounter() - lds_cnt[16 + (threadIdx.x >> 6)];
     const uint32_t ppw = wave_local ? 4u * ppwave : 256u / n_thr;
-    const uint32_t g = (P.batch_first_wg + blockIdx.x) * ppw + (wave_local ? (threadIdx.x >> 6) * ppwave : threadIdx.x / n_thr), sup_slot = g >> 8;
+    const uint32_t g = rt_batch_wg(P, blockIdx.x) * ppw + (wave_local ? (threadIdx.x >> 6) * ppwave : threadIdx.x / n_thr), sup_slot = g >> 8;
     if (sup_slot < P.n_sup) atomicAdd(&P.cost_map[P.sup_list ? P.sup_list[sup_slot] : sup_slot], (uint32_t)(dt >> 6));
   }
   wave_flush(wv, P, (uint32_t)__popcll(wave_ballot(wrote)), lds_cnt);

@@ -135,6 +135,12 @@ typedef struct rt_tuning {
    * the union of those lists instead of walking the BVH for its soft-shadow candidates -- same candidates after the
    * lanes' own beam tests, same image.  16 bytes per cell and light of device memory. */
   uint32_t no_cell_lists;
+  /* Chains a frame with secondary rays is split into (1..2; 0 = default 2).  The ray tree of a frame is a chain of launches,
+   * one per level, and a launch cannot end before its longest wavefront does; two halves of the frame's primary work list
+   * run as independent chains on two streams (the caller's and one of the library's, forked and joined with events) so that
+   * the head of one chain's launch fills the drain of the other's.  Twice the queues of half the size -- same memory, same
+   * image.  A host that keeps several frames in flight itself may prefer 1. */
+  uint32_t sub_frames;
 } rt_tuning;
 #define RT_TILE_ORDER_DEFAULT 0u
 #define RT_TILE_ORDER_ROW_MAJOR 1u

@@ -1299,6 +1299,57 @@ def test_receiver_cell_count_of_64k_plus_1_last_wavefront_owns_one_cell():
     compare(cfg, flat, ((11 * seed) % 96, (5 * seed) % 80, 64, 48))
 
 
+def test_frame_as_two_chains_equals_frame_as_one_chain():
+    """rt_tuning.sub_frames: a frame with secondary rays runs as two chains (halves of its primary work list, own queues and
+    counters, the library's own second stream) that meet in the pixel accumulator.  Same packed pixels, same planes, same ray
+    counters as the one-chain frame -- for the test scene, for a random soup whose queues must grow (seed 29: both chains are
+    rendered again), and for a frame enqueued repeatedly (the verified, unsynchronised path with grids guessed per chain)."""
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], n_cloud_sets=64, depth_override=5)
+    flat = scenes.test_scene(cfg).flatten()
+    a1, p1, s1 = gpu_render(cfg, flat, sub_frames=1)
+    a2, p2, s2 = gpu_render(cfg, flat, sub_frames=2)
+    a0, p0, s0 = gpu_render(cfg, flat)  # default = two chains
+    for a, pl, st in ((a2, p2, s2), (a0, p0, s0)):
+        assert np.array_equal(a, a1)
+        assert np.array_equal(pl["rgb"].view(np.uint32), p1["rgb"].view(np.uint32))
+        assert np.array_equal(pl["hit_id"], p1["hit_id"])
+        for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written", "rays_traced"):
+            assert st[k] == s1[k], k
+    seed = 29
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], width_override=160, height_override=128,
+                                     n_cloud_sets=16, depth_override=3, cloud_seed=seed)
+    soup = random_scene(seed, n_spheres=3 + seed % 12, n_tris=200 + 37 * (seed % 40), n_lights=2 + seed % 3, cfg=cfg)
+    win = ((11 * seed) % 96, (5 * seed) % 80, 64, 48)
+    b1, q1, t1 = gpu_render(cfg, soup, win, sub_frames=1)
+    b2, q2, t2 = gpu_render(cfg, soup, win, sub_frames=2)
+    assert np.array_equal(b1, b2) and np.array_equal(q1["rgb"].view(np.uint32), q2["rgb"].view(np.uint32))
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written", "rays_traced"):
+        assert t1[k] == t2[k], k
+    # steady state: frames of a verified shape, enqueued back to back on one stream
+    import ctypes as C
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    lib, hip = _lib.load(), _loaded_hip_runtime()
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], n_cloud_sets=64, depth_override=5)
+    ds = DeviceScene(flat, 0)
+    nbytes = cfg.width * cfg.height * 4
+    fp = C.c_void_p()
+    assert hip.hipMalloc(C.byref(fp), C.c_size_t(nbytes)) == 0 and hip.hipMemset(fp, 0, C.c_size_t(nbytes)) == 0
+    p, keep = _abi.make_params(cfg)
+    for _ in range(6):
+        _lib.check(lib.rt_render_device(ds.handle, C.byref(p), fp, None, None))
+    assert hip.hipDeviceSynchronize() == 0
+    got = np.zeros(cfg.width * cfg.height, np.uint32)
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fp, C.c_size_t(nbytes), 2) == 0
+    assert np.array_equal(got, a1)
+    st = _abi.rt_stats()
+    _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
+        assert getattr(st, k) == s1[k], k
+    ds.close()
+    assert hip.hipFree(fp) == 0
+
+
 def test_two_frames_with_secondary_rays_in_flight():
     """Two frames with reflections / refractions in flight on two streams: each owns a workspace set (ray queues, sort
     workspace, hard-pair queue, level counters, accumulator), so the levels of one fill the compute units the drains of the

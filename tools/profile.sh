@@ -11,9 +11,9 @@ OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
 # 20 timed frames + 2 warm-up + bench.py's 20 isolated frames for the roofline = 42 frames per pass, all on one stream
-# (--in-flight 1: overlapping launches would stretch each other's durations)
+# (--in-flight 1 --sub-frames 1: overlapping launches would stretch each other's durations)
 STEPS=${RT_PROFILE_STEPS:-20}
-ARGS="--steps $STEPS --warmup 2 --in-flight 1 --no-cpu-baseline --no-boundary-costs --no-other-workloads --workload $WL $@"
+ARGS="--steps $STEPS --warmup 2 --in-flight 1 --sub-frames 1 --no-cpu-baseline --no-boundary-costs --no-other-workloads --workload $WL $@"
 echo $((STEPS + 2 + (STEPS < 20 ? STEPS : 20))) > $OUT/n_frames.txt
 python3 -c "import sys; sys.path.insert(0, '$REPO'); from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib; print(_lib.load().rt_build_id().decode())" > $OUT/build_id.txt
 cd /tmp
