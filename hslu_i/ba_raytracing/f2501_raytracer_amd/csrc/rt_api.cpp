@@ -820,6 +820,13 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     if (j && !w.lane[j].stream) HIP_TRY(hipStreamCreateWithFlags(&w.lane[j].stream, hipStreamNonBlocking));
     if (j && !w.lane[j].done_ev) HIP_TRY(hipEventCreateWithFlags(&w.lane[j].done_ev, hipEventDisableTiming));
   }
+  for (uint32_t j = lanes; j < RT_LANES; j++)  // memory by need: a set that runs one chain does not keep the other chain's queues
+    if (w.lane[j].queues.p || w.lane[j].trace_ws.p || w.lane[j].hard.p) {
+      if (w.lane[j].stream) HIP_TRY(hipStreamSynchronize(w.lane[j].stream));
+      HIP_TRY(hipStreamSynchronize(stream));  // (behind the wait for the set's last frame enqueued above)
+      w.lane[j].queues.release(), w.lane[j].trace_ws.release(), w.lane[j].hard.release();
+      w.lane[j].sort_hist_clean = nullptr;
+    }
   if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, RT_LANES * 160 * 4, hipHostMallocDefault));
   if (!w.cnt_ev) HIP_TRY(hipEventCreateWithFlags(&w.cnt_ev, hipEventDisableTiming));
   if (!w.fork_ev) HIP_TRY(hipEventCreateWithFlags(&w.fork_ev, hipEventDisableTiming));
