@@ -328,9 +328,13 @@ void rt_build_bvh(const float* v1, const float* e1, const float* e2, const uint8
 
   RtNode root;
   memset(&root, 0, sizeof(root));
+  // An absent child's box is NaN: every comparison of a slab test against it is false in every copy of the tree, whatever
+  // the signs of the direction.  (An inverted infinite box -- lo = +inf, hi = -inf -- is NOT safe: a direction with all
+  // components negative turns it into the slab (-inf, +inf) on every axis; the candidate walk of rt_flags_kernel then
+  // followed RT_NODE_EMPTY of a scene without triangles into unmapped memory: fuzz variant 2, seed 11.)
   for (int a = 0; a < 3; a++) {
-    root.lo0[a] = root.lo1[a] = INFINITY;
-    root.hi0[a] = root.hi1[a] = -INFINITY;
+    root.lo0[a] = root.lo1[a] = NAN;
+    root.hi0[a] = root.hi1[a] = NAN;
   }
   root.c0 = root.c1 = RT_NODE_EMPTY;
   root.n0 = root.n1 = 0;

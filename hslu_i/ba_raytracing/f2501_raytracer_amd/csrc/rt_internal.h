@@ -45,7 +45,7 @@ struct RtThrNode {
 };
 static_assert(sizeof(RtThrNode) == 32, "threaded node must be 32 bytes");
 
-#define RT_NODE_EMPTY 0xFFFFFFFFu  // c* value of an absent child (box is inverted, never hit)
+#define RT_NODE_EMPTY 0xFFFFFFFFu  // c* value of an absent child (its box is NaN: no slab test ever passes)
 #define RT_TRI_DUPLICATE 0x80000000u  // tri_id flag: not the first reference of its triangle (slot order)
 #define RT_TRI_TRANSMISSIVE 0x40000000u  // tri_id flag (device copy): the triangle's material lets light through
 #define RT_TRI_INDEX_MASK 0x3FFFFFFFu

@@ -691,7 +691,7 @@ __device__ __forceinline__ Hit nearest_hit(const RtDevScene& sc, const RtDevPara
       } else {
         box_pair(nd, br, t_limit_slack(best.t), h0, h1, tn0, tn1);
       }
-      // (an absent child has an inverted box in every copy: never hit)
+      // (an absent child has a NaN box in every copy: no comparison passes, never hit)
       const lanemask b0 = h0 & grp;
       const lanemask b1 = h1 & grp;
       uint32_t next = RT_NODE_EMPTY;
@@ -1026,7 +1026,7 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
         h0 = box(nd.lo0, nd.hi0, tn0);
         h1 = box(nd.lo1, nd.hi1, tn1);
       }
-      // (an absent child has an inverted box in every copy: never hit)
+      // (an absent child has a NaN box in every copy: no comparison passes, never hit)
       const lanemask b0 = h0 & grp;
       const lanemask b1 = h1 & grp;
       // near-first order so that early occluders are tested first by every sample
@@ -2682,7 +2682,8 @@ __global__ __launch_bounds__(256) void rt_flags_kernel(RtDevScene sc, RtDevParam
     const V3 centre = mk(L0.x + P.cloud_centre[0], L0.y + P.cloud_centre[1], L0.z + P.cloud_centre[2]);
     // (the cell's candidate list for this light: RT_CELL_LIST_SLOTS 16-bit leaf slots, preset to 0xFFFF by the host)
     fb.list = (P.cell_list_out && have) ? P.cell_list_out + ((size_t)c * sc.n_lights + l) * RT_CELL_LIST_SLOTS : nullptr;
-    const CandList cl = collect_light_candidates<false, COLLECT_FLAGS>(sc, W, active, pm, centre, P, pm, 0.0f, RT_MAX_CANDIDATES, &fb);
+    const CandList cl = collect_light_candidates<false, COLLECT_FLAGS>(sc, W, active, pm, centre, P, pm, 0.0f, RT_MAX_CANDIDATES, &fb,
+                                                                          sc.n_triangles != 0u);  // (no triangles: no walk)
     if (fb.list && active && cl.reg > RT_CELL_LIST_SLOTS) fb.list[0] = (uint16_t)RT_CELL_LIST_OVERFLOW;
     const lanemask near_m = (lanemask)cl.count | ((lanemask)cl.spheres << 32);
     if (wave_ballot(active)) {

@@ -1299,6 +1299,22 @@ def test_receiver_cell_count_of_64k_plus_1_last_wavefront_owns_one_cell():
     compare(cfg, flat, ((11 * seed) % 96, (5 * seed) % 80, 64, 48))
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_tris", [0, 1, 3])
+def test_soft_shadows_on_scenes_with_an_empty_or_single_leaf_bvh(n_tris):
+    """Fuzz variant 2, seed 11: spheres only + soft shadows.  The BVH of such a scene is a root with two ABSENT children (a
+    single leaf: one absent child); their boxes were inverted infinite boxes, which a direction with three negative components
+    turns into the slab (-inf, +inf) on every axis -- rt_flags_kernel's candidate walk followed RT_NODE_EMPTY into unmapped
+    memory.  Absent boxes are NaN now (no comparison passes).  Lights on the far side of the spheres give cells whose segments
+    to the light point into the all-negative octant."""
+    seed = 11
+    cfg = RenderConfig.from_features(["anti_aliasing", "high_quality"], width_override=80, height_override=54, n_cloud_sets=8,
+                                     cloud_seed=seed)
+    flat = random_scene(seed, n_spheres=23, n_tris=n_tris, n_lights=3, cfg=cfg)
+    compare(cfg, flat, (5, 5, 16, 34))
+    compare(cfg, flat, (40, 10, 32, 24))
+
+
 def test_frame_as_two_chains_equals_frame_as_one_chain():
     """rt_tuning.sub_frames: a frame with secondary rays runs as two chains (halves of its primary work list, own queues and
     counters, the library's own second stream) that meet in the pixel accumulator.  Same packed pixels, same planes, same ray
