@@ -778,6 +778,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     return RT_OK;
   }
   int rc;
+  if (total_wgs == 0) return RT_OK;  // this rank owns no tile inside the window (more ranks than tiles): nothing to trace, nothing to resolve
   const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
   if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
   const size_t npix = (size_t)P.width * P.height;
@@ -893,7 +894,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       s->batch_items = std::max<uint32_t>(s->batch_items / 2u, 1u << 10);
       s->stream_verified = false;
     }
-    s->batch_items = (s->batch_items + 255u) / 256u * 256u;
+    s->batch_items = std::max<uint32_t>((s->batch_items + 255u) / 256u * 256u, 256u);
     s->q_cap = (uint32_t)std::min<uint64_t>(((uint64_t)s->q_cap + 255u) / 256u * 256u, 0xFFFFFF00ull);  // (16-byte aligned arrays behind it)
     // (more rays per level = more rays per bucket: two more key bits for 4K-sized frames: config 5 136.2 -> 133.4 ms)
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : (items >= (32ull << 20) ? RT_SORT_BITS_DEFAULT + 2u : RT_SORT_BITS_DEFAULT);

@@ -152,6 +152,22 @@ def test_tile_partition_union_equals_full():
     assert written == sf["pixels_written"]
 
 
+def test_more_ranks_than_tiles_with_secondary_rays():
+    """A 48x46 frame is ONE 48x48 ownership tile: of five ranks four own nothing.  With secondary rays such a rank sized its
+    ray queues for zero work items and divided by that (SIGFPE in the host library, found by tools/fuzz_knobs.py seed 4)."""
+    cfg = RenderConfig.from_features(["anti_aliasing", "soft_shadows", "refractions"], width_override=48, height_override=46,
+                                     n_cloud_sets=8, depth_override=3, cloud_seed=4)
+    flat = random_scene(4, n_spheres=12, n_tris=47, n_lights=1, cfg=cfg)
+    full, _, sf = gpu_render(cfg, flat)
+    acc = np.zeros_like(full)
+    written = 0
+    for rank in range(5):
+        part, _, sp = gpu_render(cfg, flat, n_ranks=5, rank=rank)
+        acc |= part
+        written += sp["pixels_written"]
+    assert np.array_equal(acc, full) and written == sf["pixels_written"]
+
+
 def test_empty_scene_and_prefilled_buffer():
     """Miss pixels are never written (image_buffer.rs:27-37): an empty scene leaves the fill intact."""
     from hslu_i.ba_raytracing.f2501_raytracer_amd import Scene
