@@ -89,6 +89,12 @@ for seed in range(first, last + 1):
         bad += 1
         print(f"{what}: union of {n_ranks} ranks DIFFERS: {int((acc != ref).sum())} packed pixels, counters "
               f"{[(k, tot[k], sref[k]) for k in COUNTERS if tot[k] != sref[k]]}")
+    # the same partition through rt_render_multi (rank-compact staging written by the kernels, gather, scatter), at a random tile size
+    ts = int(r.choice([16, 32, 48, 64]))
+    got, _ = T.render_multi(cfg, flat, n_ranks, window=win, tile_size=ts)
+    if not np.array_equal(got, ref):
+        bad += 1
+        print(f"{what}: rt_render_multi with {n_ranks} ranks, tile size {ts} DIFFERS: {int((got != ref).sum())} packed pixels")
     print(f"seed {seed} ok" if not bad else f"seed {seed} done ({bad} failures so far)")
 print(f"{bad} failures in seeds {first}..{last}")
 sys.exit(1 if bad else 0)
