@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--sub-frames", type=int, default=0, choices=[0, 1, 2],
                     help="rt_tuning.sub_frames: chains a frame with secondary rays is split into.  0 = the library's choice (two while "
                          "no other frame of the scene is running, one otherwise); profiles use 1 (chains stretch each other's launches)")
+    ap.add_argument("--phases", type=int, default=0, choices=[0, 1, 2],
+                    help="rt_tuning.phases: 0 = the library's choice, 1 = fused kernels, 2 = phase-split pipeline (csrc/rt_phases.h)")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
@@ -283,7 +285,7 @@ def main():
     t_scene = time.perf_counter()
     ds = DeviceScene(flat, device=local_rank)
     scene_create_ms = (time.perf_counter() - t_scene) * 1e3
-    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames))
+    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames, phases=args.phases))
     npix = cfg.width * cfg.height
     n_fly = args.in_flight or 2
     if args.backend == "gloo" and world > 1:

@@ -82,7 +82,7 @@ void rt_scene_destroy(rt_scene* s) {
     for (auto& l : w.lane) {
       if (l.stream) (void)hipStreamSynchronize(l.stream), (void)hipStreamDestroy(l.stream);
       if (l.done_ev) (void)hipEventDestroy(l.done_ev);
-      for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard}) b->release();
+      for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard, &l.hitrec, &l.sets}) b->release();
     }
   }
   for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags, &s->cell_lists})
@@ -439,6 +439,7 @@ int rt_validate_params(const rt_params* p) {
   if (p->tuning.sort_bits && (p->tuning.sort_bits < 12u || p->tuning.sort_bits > 24u))
     return fail(RT_ERR_INVALID_ARG, "tuning.sort_bits outside 12..24");
   if (p->tuning.sub_frames > RT_LANES) return fail(RT_ERR_INVALID_ARG, "tuning.sub_frames > %u", (unsigned)RT_LANES);
+  if (p->tuning.phases > RT_PHASES_SPLIT) return fail(RT_ERR_INVALID_ARG, "tuning.phases > %u", (unsigned)RT_PHASES_SPLIT);
   return RT_OK;
 }
 
@@ -605,6 +606,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   P->max_depth_refraction = p->max_depth_refraction;
   s->sort_bits_wanted = p->tuning.sort_bits;
   s->lanes_wanted = p->tuning.sub_frames;
+  s->phases_wanted = p->tuning.phases;
   if (p->win_w) {
     P->win_x0 = p->win_x0, P->win_y0 = p->win_y0, P->win_w = p->win_w, P->win_h = p->win_h;
   } else {
@@ -725,7 +727,8 @@ static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;  // hard ceiling; the r
 #define RT_CNT_HARD(levels) ((levels) + 2u)      // hard pairs waiting
 #define RT_CNT_HARD_STAT(levels) ((levels) + 3u) // [0] dropped pairs, [1] largest batch of pairs
 #define RT_CNT_HITS(levels, k) ((levels) + 5u + (k))  // rays of level k that hit something
-#define RT_CNT_TOTAL(levels) (2u * (levels) + 8u)
+#define RT_CNT_SETS(levels, k, c) (2u * (levels) + 8u + 3u * (k) + (c))  // phase-split pipeline: sets of class c at level k = 0 .. levels
+#define RT_CNT_TOTAL(levels) (2u * (levels) + 8u + 3u * ((levels) + 1u))
 
 // Diagnostics: RT_TRACE_LAUNCHES=1 in the environment makes every launch of a frame wait for its kernel and report it on
 // stderr (which launch of which level does not come back, with which sizes); never set in timed runs.
@@ -753,6 +756,15 @@ static uint32_t grid_for(uint64_t items, uint32_t per_wg, uint32_t cap_wgs) {
 
 static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking);
 
+// which form of the render loop a frame takes (rt_tuning.phases; RT_PHASES_DEFAULT: by frame shape)
+static bool rt_use_phases(uint32_t wanted, const RtDevParams& P, bool secondary) {
+  if (P.cost_map) return false;  // (the calibration frame of RT_TILE_ORDER_COST times the fused primary kernel)
+  if (wanted == RT_PHASES_SPLIT) return true;
+  if (wanted == RT_PHASES_FUSED) return false;
+  (void)secondary;
+  return false;
+}
+
 // A frame that fails half-way (HIP / launch error, out of memory) leaves partial sums in the pixel accumulator: mark
 // the accumulator dirty so that the next frame clears it.
 static int render_frame(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking = false) {
@@ -768,7 +780,11 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const bool secondary = (P.flags & (RT_FLAG_REFLECTIONS | RT_FLAG_REFRACTIONS)) != 0;
   const uint32_t total_wgs = rt_primary_total_wgs(P);
   s->queue_bytes = 0;
-  if (!secondary) {
+  // The phase-split pipeline (rt_phases.h; rt_tuning.phases): hit -> classify -> one kernel per class of (wavefront, light)
+  // set -> resolve, instead of the fused kernels.  Frames without secondary rays then also sum through the accumulator.
+  const bool split = rt_use_phases(s->phases_wanted, P, secondary);
+  P.resolve_counts_written = split ? 1u : 0u;
+  if (!secondary && !split) {
     P.acc = nullptr;
     P.q_out = nullptr;
     P.batch_first_wg = 0, P.batch_stride = 1, P.batch_group_log2 = 0;
@@ -779,12 +795,12 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   }
   int rc;
   if (total_wgs == 0) return RT_OK;  // this rank owns no tile inside the window (more ranks than tiles): nothing to trace, nothing to resolve
-  const uint32_t levels = P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction;
-  if (levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
+  const uint32_t levels = !secondary ? 0u : (P.max_depth_reflection > P.max_depth_refraction ? P.max_depth_reflection : P.max_depth_refraction);
+  if (secondary && levels == 0) return fail(RT_ERR_INVALID_ARG, "secondary rays enabled with depth 0");
   const size_t npix = (size_t)P.width * P.height;
   const uint64_t items = (uint64_t)total_wgs * 256u;  // primary work items (threads) of the frame
   // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs
-  const bool hard = P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
+  const bool hard = secondary && P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);
   // ---- chains.  The ray tree of a frame is a chain of launches, one per level, each with a drain of its own (a launch
@@ -803,7 +819,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->calm_frames = busy ? 0u : std::min<uint32_t>(s->calm_frames + 1u, 1u << 30);
     if (s->calm_frames < 8u) lanes = 1;
   }
-  if (forced_chunk_log2 || items < (1ull << 16)) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
+  if (forced_chunk_log2 || items < (1ull << 16) || !secondary) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
   // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
   // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
   int wsi = s->cur_block;
@@ -822,13 +838,13 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     if (j && !w.lane[j].done_ev) HIP_TRY(hipEventCreateWithFlags(&w.lane[j].done_ev, hipEventDisableTiming));
   }
   for (uint32_t j = lanes; j < RT_LANES; j++)  // memory by need: a set that runs one chain does not keep the other chain's queues
-    if (w.lane[j].queues.p || w.lane[j].trace_ws.p || w.lane[j].hard.p) {
+    if (w.lane[j].queues.p || w.lane[j].trace_ws.p || w.lane[j].hard.p || w.lane[j].hitrec.p || w.lane[j].sets.p) {
       if (w.lane[j].stream) HIP_TRY(hipStreamSynchronize(w.lane[j].stream));
       HIP_TRY(hipStreamSynchronize(stream));  // (behind the wait for the set's last frame enqueued above)
-      w.lane[j].queues.release(), w.lane[j].trace_ws.release(), w.lane[j].hard.release();
+      w.lane[j].queues.release(), w.lane[j].trace_ws.release(), w.lane[j].hard.release(), w.lane[j].hitrec.release(), w.lane[j].sets.release();
       w.lane[j].sort_hist_clean = nullptr;
     }
-  if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, RT_LANES * 160 * 4, hipHostMallocDefault));
+  if (!w.cnt_host) HIP_TRY(hipHostMalloc((void**)&w.cnt_host, RT_LANES * RT_CNT_STRIDE * 4, hipHostMallocDefault));
   if (!w.cnt_ev) HIP_TRY(hipEventCreateWithFlags(&w.cnt_ev, hipEventDisableTiming));
   if (!w.fork_ev) HIP_TRY(hipEventCreateWithFlags(&w.fork_ev, hipEventDisableTiming));
 
@@ -843,6 +859,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   key.tables = s->tables_version;
   memcpy(key.f, P.focus, 12), key.f[3] = P.fw, key.f[4] = P.fh, key.f[5] = P.fd, key.f[6] = P.eps_distance, key.f[7] = P.air_ior;
   key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup, key.lanes = lanes;
+  key.split = split, key.sort_bits = s->sort_bits_wanted, key.lists_on = P.cell_lists != nullptr;
   if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
     s->stream_key = key;
     s->stream_verified = false;
@@ -886,7 +903,14 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     size_t budget = RT_QUEUE_BUDGET, free_b = 0, total_b = 0;
     const size_t held = w.bytes() - w.acc.cap;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
-    auto bytes_for = [&](uint64_t q, uint64_t h) { return (size_t)lanes * (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)); };
+    // (phase-split pipeline: 8 bytes of hit record per primary work item of a batch + the (wavefront, light) set records, dense by
+    // set id: 32-byte header, 64-dword candidate list, a slot in each of the three class queues)
+    auto set_cap_for = [&](uint64_t q, uint64_t batch) { return (uint32_t)((std::max<uint64_t>(levels ? q : 0u, batch + 64u * 256u) / 64u + 4u) * std::max<uint32_t>(s->dev.n_lights, 1u)); };
+    auto bytes_for = [&](uint64_t q, uint64_t h) {
+      size_t b = levels ? (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)) : 0u;
+      if (split) b += (size_t)(s->batch_items + 64u * 256u) * 8u + (size_t)set_cap_for(q, s->batch_items) * (32u + 256u + 12u);
+      return (size_t)lanes * b;
+    };
     while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
       // does not fit: smaller primary batches, queues and pair buffer in proportion
       s->q_cap = std::max<uint32_t>(s->q_cap / 2u, 1u << 16);
@@ -900,10 +924,16 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : (items >= (32ull << 20) ? RT_SORT_BITS_DEFAULT + 2u : RT_SORT_BITS_DEFAULT);
     const uint32_t n_buckets = 1u << P.sort_bits;
     rc = RT_OK;
+    const uint32_t set_cap = split ? set_cap_for(s->q_cap, s->batch_items) : 0u;
+    const size_t hitrec_items = (size_t)s->batch_items + 64u * 256u;  // (an interleaved chain's launch is rounded up to whole groups)
     for (uint32_t j = 0; j < lanes && rc == RT_OK; j++) {
-      rc = w.lane[j].queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
-      if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+      if (levels) {
+        rc = w.lane[j].queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
+        if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+      }
       if (rc == RT_OK && hard) rc = w.lane[j].hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
+      if (rc == RT_OK && split) rc = w.lane[j].hitrec.ensure(hitrec_items * 8u);
+      if (rc == RT_OK && split) rc = w.lane[j].sets.ensure((size_t)set_cap * (32u + 256u + 12u) + 256u);
     }
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
       s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
@@ -937,7 +967,14 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       Q.sort_hist = Q.sh_idx + s->q_cap;
       Q.sort_offs = Q.sort_hist + n_buckets;
       Q.sort_tile = Q.sort_offs + n_buckets;
-      if (L.sort_hist_clean != (void*)Q.sort_hist || L.sort_hist_buckets != n_buckets) {
+      if (split) {
+        Q.hitrec = (uint2*)L.hitrec.p;
+        Q.set_hdr = (uint4*)L.sets.p;                                        // [set_cap][2] uint4
+        Q.set_list = (uint32_t*)L.sets.p + (size_t)set_cap * 8u;             // [set_cap][64]
+        Q.set_q = (uint32_t*)L.sets.p + (size_t)set_cap * (8u + 64u);        // [3][set_cap]
+        Q.set_cap = set_cap;
+      }
+      if (levels && (L.sort_hist_clean != (void*)Q.sort_hist || L.sort_hist_buckets != n_buckets)) {
         // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
         HIP_TRY(hipMemsetAsync(Q.sort_hist, 0, (size_t)n_buckets * 4, stream));
         L.sort_hist_clean = (void*)Q.sort_hist;
@@ -993,11 +1030,38 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         Q.batch_first_wg = w0, Q.batch_stride = 1, Q.batch_group_log2 = 0;
       }
       Q.q_in = nullptr, Q.q_in_count = nullptr;
-      Q.q_out = q[j][0];
+      Q.q_out = levels ? q[j][0] : nullptr;
       Q.q_out_count = counts[j] + RT_CNT_LEVEL(1);
-      hipError_t e = (hipError_t)rt_launch_primary(s->dev, Q, nw, st);
-      if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-      trace_point(st, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
+      hipError_t e;
+      // the (wavefront, light) sets K2 queued for level k, one launch per class (grids: last frame's counts of this shape)
+      auto run_sets = [&](uint32_t k) -> int {
+        for (int c = 0; c < 3; c++) {
+          if (c == 0 && rt_phases_arrive_inline()) continue;  // (ARRIVE sets are finished by K2 itself in this build)
+          const uint32_t cap_sets = (set_cap + 3u) / 4u;
+          const uint32_t g = guess ? grid_for(s->est[j][RT_CNT_SETS(levels, k, c)], 4u, cap_sets) : cap_sets;
+          hipError_t es = (hipError_t)rt_launch_sets(s->dev, Q, k == 0, c, g, st);
+          if (es != hipSuccess) return fail(RT_ERR_HIP, "set-kernel launch failed: %s", hipGetErrorString(es));
+          trace_point(st, "rt_sets kernel: level, class, workgroups", k, (uint32_t)c, g);
+        }
+        return RT_OK;
+      };
+      if (split) {
+        if (lane_batches[j] > 1) HIP_TRY(hipMemsetAsync(counts[j] + RT_CNT_SETS(levels, 0, 0), 0, (size_t)3 * (levels + 1) * 4, st));  // next batch: its set counters
+        Q.set_count = counts[j] + RT_CNT_SETS(levels, 0, 0);
+        Q.set_items = nw * 256u;
+        if ((size_t)nw * 256u > hitrec_items) return fail(RT_ERR_HIP, "internal: primary batch of %u workgroups exceeds the hit-record buffer", nw);
+        e = (hipError_t)rt_launch_hit(s->dev, Q, nw, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_hit_kernel: first workgroup, workgroups", w0, nw);
+        e = (hipError_t)rt_launch_classify(s->dev, Q, true, nw, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_classify0_kernel: first workgroup, workgroups, set capacity", w0, nw, set_cap);
+        if ((rc = run_sets(0)) != RT_OK) return rc;
+      } else {
+        e = (hipError_t)rt_launch_primary(s->dev, Q, nw, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
+      }
       for (uint32_t k = 1; k <= levels; k++) {
         if ((rc = run_hard(j, st)) != RT_OK) return rc;  // the pairs the launch before deferred
         Q.q_in = q[j][(k - 1u) & 1u];
@@ -1018,9 +1082,17 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         e = (hipError_t)rt_launch_sort(Q, g_rays, st);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
         trace_point(st, "sort kernels: level, buckets, chain", k, n_buckets, j);
-        e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
-        if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
-        trace_point(st, "rt_shade_kernel: level, workgroups, chain", k, g_hits, j);
+        if (split) {
+          Q.set_count = counts[j] + RT_CNT_SETS(levels, k, 0);
+          e = (hipError_t)rt_launch_classify(s->dev, Q, false, g_hits, st);
+          if (e != hipSuccess) return fail(RT_ERR_HIP, "classify launch failed: %s", hipGetErrorString(e));
+          trace_point(st, "rt_classify_kernel: level, workgroups, chain", k, g_hits, j);
+          if ((rc = run_sets(k)) != RT_OK) return rc;
+        } else {
+          e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
+          if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+          trace_point(st, "rt_shade_kernel: level, workgroups, chain", k, g_hits, j);
+        }
       }
       if ((rc = run_hard(j, st)) != RT_OK) return rc;  // pairs deferred by the last level's shading
     }
@@ -1042,7 +1114,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     }
     if (!w.cnt_pending) {
       for (uint32_t j = 0; j < lanes; j++)
-        HIP_TRY(hipMemcpyAsync(w.cnt_host + (size_t)j * 160u, counts[j], (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(w.cnt_host + (size_t)j * RT_CNT_STRIDE, counts[j], (size_t)n_cnt * 4, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipEventRecord(w.cnt_ev, stream));
       w.cnt_pending = true;
       w.cnt_host_levels = levels;
@@ -1054,7 +1126,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     w.cnt_pending = false;
     uint32_t dropped = 0, dropped_pairs = 0, need = 0, need_pairs = 0;
     for (uint32_t j = 0; j < lanes; j++) {
-      const uint32_t* c = w.cnt_host + (size_t)j * 160u;
+      const uint32_t* c = w.cnt_host + (size_t)j * RT_CNT_STRIDE;
       dropped += c[RT_CNT_OVERFLOW], dropped_pairs += c[RT_CNT_HARD_STAT(levels)];
       for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, c[RT_CNT_LEVEL(k)]);
       need_pairs = std::max(need_pairs, c[RT_CNT_HARD_STAT(levels) + 1u]);

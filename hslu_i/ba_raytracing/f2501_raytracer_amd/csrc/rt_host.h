@@ -25,6 +25,8 @@ int rt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3))
 #define RT_SLOTS 4
 // chains a frame with secondary rays is split into (rt_tuning.sub_frames)
 #define RT_LANES 2
+// dwords of a chain's device-side counter block (levels <= 64: 2 * 64 + 8 level counters + 3 * 65 set-class counters)
+#define RT_CNT_STRIDE 384
 
 struct DevBuf {
   void* p = nullptr;
@@ -62,7 +64,7 @@ struct EventPair {  // destroyed on every return path
 // verified frame renders without a synchronisation
 struct StreamKey {
   uint32_t width, height, flags, aa_rays, aa_unique, light_mult, depth_refl, depth_refr, win[4], tile_size, n_ranks, rank, traversal,
-      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup, lanes;
+      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup, lanes, split, sort_bits, lists_on;
   float f[8];
 };
 
@@ -81,6 +83,7 @@ struct rt_scene {
   // set (forked / joined with events).  The chains meet in the pixel accumulator.
   struct Lane {
     DevBuf queues, trace_ws, hard, qcount;
+    DevBuf hitrec, sets;              // phase-split pipeline: hit records of the primary launch, (wavefront, light) set records
     void* sort_hist_clean = nullptr;  // the histogram (address, size) that is known to be zero
     uint32_t sort_hist_buckets = 0;
     hipStream_t stream = nullptr;     // chains 1..: their own stream
@@ -90,13 +93,13 @@ struct rt_scene {
     Lane lane[RT_LANES];
     DevBuf acc;
     size_t acc_pixels = 0;            // pixels the (zeroed) accumulator currently covers; 0 = must be cleared before use
-    uint32_t* cnt_host = nullptr;     // pinned, [RT_LANES][160]: asynchronous read-back of the chains' counters
+    uint32_t* cnt_host = nullptr;     // pinned, [RT_LANES][RT_CNT_STRIDE]: asynchronous read-back of the chains' counters
     hipEvent_t cnt_ev = nullptr, fork_ev = nullptr;
     bool cnt_pending = false, cnt_host_valid = false;
     uint32_t cnt_host_levels = 0, cnt_host_lanes = 0;
     size_t bytes() const {
       size_t b = acc.cap;
-      for (const Lane& l : lane) b += l.queues.cap + l.trace_ws.cap + l.hard.cap;
+      for (const Lane& l : lane) b += l.queues.cap + l.trace_ws.cap + l.hard.cap + l.hitrec.cap + l.sets.cap;
       return b;
     }
   } ws[RT_SLOTS];
@@ -111,10 +114,11 @@ struct rt_scene {
   uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // per chain: rays per queue, pairs; primary work items per batch
   StreamKey stream_key{};
   bool stream_verified = false;  // a frame of this key ran without dropping a ray or a pair
-  uint32_t est[RT_LANES][160] = {{0}};  // the counters of the last complete frame of this key, per chain (grids of the next one)
+  uint32_t est[RT_LANES][RT_CNT_STRIDE] = {{0}};  // the counters of the last complete frame of this key, per chain (grids of the next one)
   bool est_valid = false;
   uint32_t sort_bits_wanted = 0;    // rt_tuning.sort_bits of the current frame (0 = default)
   uint32_t lanes_wanted = 0;        // rt_tuning.sub_frames of the current frame (0 = default)
+  uint32_t phases_wanted = 0;       // rt_tuning.phases of the current frame (0 = default)
   uint32_t calm_frames = 1u << 30;  // frames enqueued in a row while no other frame of the scene was running (sub_frames = 0: auto)
   uint32_t tables_version = 0;      // bumped whenever a parameter table (AA samples, light clouds, flags, tile list) is uploaded
   float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)

@@ -186,6 +186,15 @@ struct RtDevParams {
   uint32_t* cost_map;
   // Morton key of a secondary hit point: q = (p - morton_lo) * morton_scale in [0, 1024)^3 (scene AABB, host)
   float morton_lo[3], morton_scale[3];
+  // ---- phase-split pipeline (rt_phases.h; all nullptr / 0 in the fused pipeline) -----------------------------------------
+  uint2* hitrec;        // K1 -> K2 / K3: {bits(t), hit id or -1} per primary work item of the launch (launched workgroup * 256 + thread)
+  uint4* set_hdr;       // K2 -> K3: 2 x uint4 per (wavefront, light) set: {first item, light, candidate count, sphere mask} {lanes in use, 0, 0}
+  uint32_t* set_list;   // 64 dwords per set: lane i = i-th candidate leaf slot (LIST sets only)
+  uint32_t* set_q;      // [3][set_cap]: the set ids of each class (ARRIVE, LIST, WALK), appended by K2
+  uint32_t* set_count;  // device, [3]: sets per class of this level
+  uint32_t set_cap;     // set ids are (first item / 64) * n_lights + light < set_cap: a class queue cannot overflow
+  uint32_t set_items;   // level 0: work items of the launch (K3 re-derives a lane's camera ray from its item index)
+  uint32_t resolve_counts_written;  // 1: rt_resolve_kernel counts the written pixels (the phase kernels do not)
 };
 
 #define RT_QUEUE_QUADS 4u   // float4 per ray record
@@ -210,6 +219,11 @@ int rt_launch_shade(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, 
 int rt_launch_hard(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
 int rt_launch_resolve(const RtDevParams& p, void* stream);
 int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream);
+// phase-split pipeline (rt_phases.h): level0 = the items are primary work items (else: the level's hits in hit-point order)
+int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
+int rt_launch_classify(const RtDevScene& sc, const RtDevParams& p, bool level0, uint32_t n_wgs, void* stream);
+int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int cls, uint32_t n_wgs, void* stream);
+bool rt_phases_arrive_inline();  // this build's K2 finishes ARRIVE sets itself (no ARRIVE launches)
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);
 // multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame
 int rt_launch_scatter(uint32_t* argb, const uint32_t* recv, const uint32_t* rank_off, const uint32_t* tile_slot, uint32_t width,

@@ -2586,7 +2586,10 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtDevParams P) {
     a[0] = a[1] = a[2] = a[3] = 0;
     wrote = 1;
   }
-  (void)wrote;
+  if (P.resolve_counts_written && P.counters) {  // (the phase kernels do not count pixels: one atomic per wavefront here)
+    const uint32_t nw = (uint32_t)__popcll(wave_ballot(wrote != 0ull));
+    if (nw && (threadIdx.x & 63u) == 0) atomicAdd(&P.counters[(size_t)(blockIdx.x % RT_COUNTER_REPLICAS) * 16u + 4u], (unsigned long long)nw);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2702,7 +2705,45 @@ __global__ __launch_bounds__(256) void rt_selftest_math_kernel(const float* in, 
   out_rcp[i] = exact_rcp(in[i]);
 }
 
+#include "rt_phases.h"
+
 }  // namespace
+
+bool rt_phases_arrive_inline() { return RT_ARRIVE_INLINE != 0; }
+
+int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) return 0;
+  hipLaunchKernelGGL(rt_hit_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_classify(const RtDevScene& sc, const RtDevParams& p, bool level0, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) {
+    if (level0) return 0;
+    n_wgs = 1;
+  }
+  if (level0)
+    hipLaunchKernelGGL(rt_classify0_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else
+    hipLaunchKernelGGL(rt_classify_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  return (int)hipGetLastError();
+}
+
+int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int cls, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) n_wgs = 1;
+  const dim3 g(n_wgs), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (level0) {
+    if (cls == SET_ARRIVE) hipLaunchKernelGGL(rt_sets0_arrive_kernel, g, b, 0, st, sc, p);
+    else if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets0_list_kernel, g, b, 0, st, sc, p);
+    else hipLaunchKernelGGL(rt_sets0_walk_kernel, g, b, 0, st, sc, p);
+  } else {
+    if (cls == SET_ARRIVE) hipLaunchKernelGGL(rt_sets_arrive_kernel, g, b, 0, st, sc, p);
+    else if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets_list_kernel, g, b, 0, st, sc, p);
+    else hipLaunchKernelGGL(rt_sets_walk_kernel, g, b, 0, st, sc, p);
+  }
+  return (int)hipGetLastError();
+}
 
 int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream) {
   if (p.n_cells == 0) return 0;

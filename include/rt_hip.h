@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3u
+#define RT_ABI_VERSION 4u
 
 /* ---- error codes -------------------------------------------------------------------------- */
 #define RT_OK 0
@@ -141,7 +141,16 @@ typedef struct rt_tuning {
    * the head of one chain's launch fills the drain of the other's.  Twice the queues of half the size -- same memory, same
    * image.  A host that keeps several frames in flight itself may prefer 1. */
   uint32_t sub_frames;
+  /* Form of the render loop (RT_PHASES_*).  FUSED: one kernel per ray-tree level runs nearest hit, the five lights' shadow
+   * classification and N-sample loops, shading and child spawning.  SPLIT: the same work as phase kernels -- hit -> per-hit
+   * classification into queues of (wavefront, light) sets -> one kernel per class of set -> resolve (csrc/rt_phases.h); the
+   * work item of the dominant kernels is a (wavefront, light) set, a fifth of a fused wavefront's.  Same integers in the pixel
+   * accumulator, hence the same frame.  0 = the library's choice for the frame shape. */
+  uint32_t phases;
 } rt_tuning;
+#define RT_PHASES_DEFAULT 0u
+#define RT_PHASES_FUSED 1u
+#define RT_PHASES_SPLIT 2u
 #define RT_TILE_ORDER_DEFAULT 0u
 #define RT_TILE_ORDER_ROW_MAJOR 1u
 #define RT_TILE_ORDER_COST 2u
