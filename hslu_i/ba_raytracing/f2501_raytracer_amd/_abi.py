@@ -12,7 +12,7 @@ RT_FLAG_REFLECTIONS, RT_FLAG_REFRACTIONS, RT_FLAG_BACKFACE_CULLING, RT_FLAG_ANTI
 RT_TRAVERSAL_BVH, RT_TRAVERSAL_LINEAR = 0, 1
 RT_CAND_CAP_NONE = 0xFFFFFFFF
 RT_TILE_ORDER_DEFAULT, RT_TILE_ORDER_ROW_MAJOR, RT_TILE_ORDER_COST = 0, 1, 2
-RT_PHASES_DEFAULT, RT_PHASES_FUSED, RT_PHASES_SPLIT = 0, 1, 2
+RT_PHASES_DEFAULT, RT_PHASES_FUSED, RT_PHASES_SPLIT, RT_PHASES_FUSED_DEFER = 0, 1, 2, 3
 (RT_NOTE_RECV_FLAGS_OFF_LIGHTS, RT_NOTE_RECV_FLAGS_OFF_CULLING, RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL, RT_NOTE_RECV_FLAGS_OFF_TUNING,
  RT_NOTE_RECV_FLAGS_OFF_SCENE, RT_NOTE_HARD_PAIRS_OFF, RT_NOTE_FRAME_BATCHED, RT_NOTE_CELL_LISTS_OFF) = 1, 2, 4, 8, 16, 32, 64, 128
 

@@ -439,7 +439,7 @@ int rt_validate_params(const rt_params* p) {
   if (p->tuning.sort_bits && (p->tuning.sort_bits < 12u || p->tuning.sort_bits > 24u))
     return fail(RT_ERR_INVALID_ARG, "tuning.sort_bits outside 12..24");
   if (p->tuning.sub_frames > RT_LANES) return fail(RT_ERR_INVALID_ARG, "tuning.sub_frames > %u", (unsigned)RT_LANES);
-  if (p->tuning.phases > RT_PHASES_SPLIT) return fail(RT_ERR_INVALID_ARG, "tuning.phases > %u", (unsigned)RT_PHASES_SPLIT);
+  if (p->tuning.phases > RT_PHASES_FUSED_DEFER) return fail(RT_ERR_INVALID_ARG, "tuning.phases > %u", (unsigned)RT_PHASES_FUSED_DEFER);
   return RT_OK;
 }
 
@@ -784,7 +784,10 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   // set -> resolve, instead of the fused kernels.  Frames without secondary rays then also sum through the accumulator.
   const bool split = rt_use_phases(s->phases_wanted, P, secondary);
   P.resolve_counts_written = split ? 1u : 0u;
-  if (!secondary && !split) {
+  // RT_PHASES_FUSED_DEFER: the fused kernels, but a frame without secondary rays also sums through the accumulator, so that its
+  // incoherent (wavefront, light) sets can be deferred to rt_hard_kernel like those of a frame with secondary rays
+  const bool defer = !secondary && !split && !P.cost_map && s->phases_wanted == RT_PHASES_FUSED_DEFER && P.light_mult > 1;
+  if (!secondary && !split && !defer) {
     P.acc = nullptr;
     P.q_out = nullptr;
     P.batch_first_wg = 0, P.batch_stride = 1, P.batch_group_log2 = 0;
@@ -800,7 +803,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const size_t npix = (size_t)P.width * P.height;
   const uint64_t items = (uint64_t)total_wgs * 256u;  // primary work items (threads) of the frame
   // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs
-  const bool hard = secondary && P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
+  const bool hard = (secondary || split || defer) && P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);
   // ---- chains.  The ray tree of a frame is a chain of launches, one per level, each with a drain of its own (a launch
@@ -819,7 +822,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->calm_frames = busy ? 0u : std::min<uint32_t>(s->calm_frames + 1u, 1u << 30);
     if (s->calm_frames < 8u) lanes = 1;
   }
-  if (forced_chunk_log2 || items < (1ull << 16) || !secondary) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
+  if (forced_chunk_log2 || items < (1ull << 16) || (!secondary && !s->lanes_wanted)) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
   // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
   // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
   int wsi = s->cur_block;
@@ -859,7 +862,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   key.tables = s->tables_version;
   memcpy(key.f, P.focus, 12), key.f[3] = P.fw, key.f[4] = P.fh, key.f[5] = P.fd, key.f[6] = P.eps_distance, key.f[7] = P.air_ior;
   key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup, key.lanes = lanes;
-  key.split = split, key.sort_bits = s->sort_bits_wanted, key.lists_on = P.cell_lists != nullptr;
+  key.split = (split ? 1u : 0u) | (defer ? 2u : 0u), key.sort_bits = s->sort_bits_wanted, key.lists_on = P.cell_lists != nullptr;
   if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
     s->stream_key = key;
     s->stream_verified = false;
@@ -905,10 +908,10 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (size_t)((double)(free_b + held) * 0.5));
     // (phase-split pipeline: 8 bytes of hit record per primary work item of a batch + the (wavefront, light) set records, dense by
     // set id: 32-byte header, 64-dword candidate list, a slot in each of the three class queues)
-    auto set_cap_for = [&](uint64_t q, uint64_t batch) { return (uint32_t)((std::max<uint64_t>(levels ? q : 0u, batch + 64u * 256u) / 64u + 4u) * std::max<uint32_t>(s->dev.n_lights, 1u)); };
+    auto set_cap_for = [&](uint64_t q, uint64_t batch) { return (uint32_t)(((std::max<uint64_t>(levels ? q : 0u, batch + 64u * 256u) / 64u + 4u) * std::max<uint32_t>(s->dev.n_lights, 1u) + 15u) & ~7ull); };
     auto bytes_for = [&](uint64_t q, uint64_t h) {
       size_t b = levels ? (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)) : 0u;
-      if (split) b += (size_t)(s->batch_items + 64u * 256u) * 8u + (size_t)set_cap_for(q, s->batch_items) * (32u + 256u + 12u);
+      if (split) b += (size_t)(s->batch_items + 64u * 256u) * 8u + (size_t)set_cap_for(q, s->batch_items) * (32u + 256u + 12u + 1u);
       return (size_t)lanes * b;
     };
     while (bytes_for(s->q_cap, s->hard_cap) > budget && s->q_cap > (1u << 16)) {
@@ -933,7 +936,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       }
       if (rc == RT_OK && hard) rc = w.lane[j].hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
       if (rc == RT_OK && split) rc = w.lane[j].hitrec.ensure(hitrec_items * 8u);
-      if (rc == RT_OK && split) rc = w.lane[j].sets.ensure((size_t)set_cap * (32u + 256u + 12u) + 256u);
+      if (rc == RT_OK && split) rc = w.lane[j].sets.ensure((size_t)set_cap * (32u + 256u + 12u + 1u) + 256u);
     }
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
       s->q_cap /= 2u, s->hard_cap = hard ? std::max<uint32_t>(s->hard_cap / 2u, 1u << 16) : 0u;
@@ -972,7 +975,9 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         Q.set_hdr = (uint4*)L.sets.p;                                        // [set_cap][2] uint4
         Q.set_list = (uint32_t*)L.sets.p + (size_t)set_cap * 8u;             // [set_cap][64]
         Q.set_q = (uint32_t*)L.sets.p + (size_t)set_cap * (8u + 64u);        // [3][set_cap]
+        Q.set_cls = (uint8_t*)((uint32_t*)L.sets.p + (size_t)set_cap * (8u + 64u + 3u));  // [set_cap] bytes
         Q.set_cap = set_cap;
+        Q.set_lights = s->dev.n_lights;
       }
       if (levels && (L.sort_hist_clean != (void*)Q.sort_hist || L.sort_hist_buckets != n_buckets)) {
         // a fresh (moved, resized) histogram: zero it once; every use leaves it zero
@@ -1034,7 +1039,12 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       Q.q_out_count = counts[j] + RT_CNT_LEVEL(1);
       hipError_t e;
       // the (wavefront, light) sets K2 queued for level k, one launch per class (grids: last frame's counts of this shape)
-      auto run_sets = [&](uint32_t k) -> int {
+      auto run_sets = [&](uint32_t k, uint32_t n_sets_host) -> int {
+        // class bytes -> class queues (level 0: the launch's set ids are known here; deeper levels: from the device-side hit count)
+        const uint32_t n_sets_guess = k == 0 ? n_sets_host : (guess ? (s->est[j][RT_CNT_HITS(levels, k)] / 64u + 2u) * s->dev.n_lights : set_cap);
+        Q.set_n = k == 0 ? n_sets_host : 0u;
+        hipError_t ec = (hipError_t)rt_launch_compact(Q, std::min<uint32_t>((n_sets_guess + 2047u) / 2048u + 1u, (set_cap + 2047u) / 2048u), st);
+        if (ec != hipSuccess) return fail(RT_ERR_HIP, "compaction launch failed: %s", hipGetErrorString(ec));
         for (int c = 0; c < 3; c++) {
           if (c == 0 && rt_phases_arrive_inline()) continue;  // (ARRIVE sets are finished by K2 itself in this build)
           const uint32_t cap_sets = (set_cap + 3u) / 4u;
@@ -1056,7 +1066,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         e = (hipError_t)rt_launch_classify(s->dev, Q, true, nw, st);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         trace_point(st, "rt_classify0_kernel: first workgroup, workgroups, set capacity", w0, nw, set_cap);
-        if ((rc = run_sets(0)) != RT_OK) return rc;
+        if ((rc = run_sets(0, nw * 4u * s->dev.n_lights)) != RT_OK) return rc;
       } else {
         e = (hipError_t)rt_launch_primary(s->dev, Q, nw, st);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -1087,7 +1097,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
           e = (hipError_t)rt_launch_classify(s->dev, Q, false, g_hits, st);
           if (e != hipSuccess) return fail(RT_ERR_HIP, "classify launch failed: %s", hipGetErrorString(e));
           trace_point(st, "rt_classify_kernel: level, workgroups, chain", k, g_hits, j);
-          if ((rc = run_sets(k)) != RT_OK) return rc;
+          if ((rc = run_sets(k, 0u)) != RT_OK) return rc;
         } else {
           e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
           if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));

@@ -191,6 +191,9 @@ struct RtDevParams {
   uint4* set_hdr;       // K2 -> K3: 2 x uint4 per (wavefront, light) set: {first item, light, candidate count, sphere mask} {lanes in use, 0, 0}
   uint32_t* set_list;   // 64 dwords per set: lane i = i-th candidate leaf slot (LIST sets only)
   uint32_t* set_q;      // [3][set_cap]: the set ids of each class (ARRIVE, LIST, WALK), appended by K2
+  uint8_t* set_cls;     // [set_cap]: class + 1 of every set id K2 wrote (0 = none; every wavefront of K2 clears its own first), input of rt_compact_kernel
+  uint32_t set_n;       // rt_compact_kernel: set ids of the launch (level 0), 0 = from the level's device-side hit count
+  uint32_t set_lights;  // ... = n_lights
   uint32_t* set_count;  // device, [3]: sets per class of this level
   uint32_t set_cap;     // set ids are (first item / 64) * n_lights + light < set_cap: a class queue cannot overflow
   uint32_t set_items;   // level 0: work items of the launch (K3 re-derives a lane's camera ray from its item index)
@@ -222,6 +225,7 @@ int rt_launch_flags(const RtDevScene& sc, const RtDevParams& p, void* stream);
 // phase-split pipeline (rt_phases.h): level0 = the items are primary work items (else: the level's hits in hit-point order)
 int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream);
 int rt_launch_classify(const RtDevScene& sc, const RtDevParams& p, bool level0, uint32_t n_wgs, void* stream);
+int rt_launch_compact(const RtDevParams& p, uint32_t n_wgs, void* stream);
 int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int cls, uint32_t n_wgs, void* stream);
 bool rt_phases_arrive_inline();  // this build's K2 finishes ARRIVE sets itself (no ARRIVE launches)
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);

@@ -2729,6 +2729,12 @@ int rt_launch_classify(const RtDevScene& sc, const RtDevParams& p, bool level0, 
   return (int)hipGetLastError();
 }
 
+int rt_launch_compact(const RtDevParams& p, uint32_t n_wgs, void* stream) {
+  if (n_wgs == 0) n_wgs = 1;
+  hipLaunchKernelGGL(rt_compact_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
 int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int cls, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) n_wgs = 1;
   const dim3 g(n_wgs), b(256);

@@ -202,11 +202,18 @@ __device__ __forceinline__ ItemHit load_item(const RtDevScene& sc, const RtDevPa
 // Adds a lane's fixed-point term to its pixel.  Level 0 with the samples of a pixel in one wavefront: the terms of a pixel
 // meet in the wavefront's LDS block and its first lane issues the atomics (3 per pixel instead of 3 per sample; integer
 // sums, so the grouping cannot change the result).  Otherwise one lane, one pixel.
+#ifndef RT_AB_NO_ATOMICS
+#define RT_AB_NO_ATOMICS 0  /* timing experiment only (wrong image): the phase kernels add nothing to the pixel accumulator */
+#endif
 template <bool L0>
 __device__ __forceinline__ void add_terms(const RtDevParams& P, long long* lds_fx /* this wavefront's [3][64] */, const ItemHit& it, bool on,
                                           long long fx, long long fy, long long fz) {
   const bool aa = (P.flags & RT_FLAG_ANTI_ALIASING) && P.aa_rays > 0;
   const uint32_t n_thr = aa ? P.aa_unique : 1u;
+  if (RT_AB_NO_ATOMICS) {  // (the terms stay live -- the store never happens -- so the sample loops are not optimised away)
+    if (on && (fx ^ fy ^ fz) == 0x7FFFFFFFFFFFFFF1ll) P.acc[0] = fx;
+    return;
+  }
   if (L0 && n_thr > 1u && rt_primary_wave_local(n_thr)) {
     const uint32_t lane = threadIdx.x & 63u;
     lds_fx[lane] = on ? fx * (long long)it.mult : 0ll;
@@ -234,13 +241,51 @@ struct SetRec {
   lanemask use_m;
 };
 __device__ __forceinline__ void set_write(const RtDevParams& P, uint32_t set_id, int cls, const SetRec& s, uint32_t cand_reg) {
+  // (no queue slot is taken here: one returning atomic per set on ONE counter serialises the whole launch -- 1.5 M of them
+  // cost config 3 more than 5 ms, r04c.  The set's class goes into a dense byte array; rt_compact_kernel builds the class
+  // queues from it with one atomic per 64 sets.)
   if ((threadIdx.x & 63u) == 0) {
     P.set_hdr[2u * (size_t)set_id] = make_uint4(s.item_base, s.light, s.count, s.spheres);
     P.set_hdr[2u * (size_t)set_id + 1u] = make_uint4((uint32_t)s.use_m, (uint32_t)(s.use_m >> 32), 0u, 0u);
-    const uint32_t at = atomicAdd(&P.set_count[cls], 1u);
-    P.set_q[(size_t)cls * P.set_cap + at] = set_id;  // (every set id exists once: a class queue cannot overflow)
+    P.set_cls[set_id] = (uint8_t)(cls + 1);
   }
   if (cls == SET_LIST) P.set_list[(size_t)set_id * 64u + (threadIdx.x & 63u)] = cand_reg;
+}
+
+// class bytes (0 = no set; every wavefront of K2 clears its own before it classifies) -> the three class queues: one thread per set id, ballot compaction, one atomic per wavefront
+// and class.  set_n = 0: the level's set ids end at ceil(hits / 64) * lights (device-side count).
+__global__ __launch_bounds__(256) void rt_compact_kernel(RtDevParams P) {
+  // 8 set ids per thread (one 8-byte load): 512 ids per wavefront and one atomic per wavefront and class -- the atomics all
+  // hit three counters, ~3 ns each whatever else happens (r04d: 0.21 ms for 1.5 M ids at 64 per wavefront)
+  const uint32_t n = P.set_n ? P.set_n : ((uload(P.sort_hits) + 63u) / 64u) * P.set_lights;
+  const uint32_t n_up = (n + 511u) & ~511u;  // (whole wavefronts: the votes below need every lane)
+  for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 8u; i < n_up; i += gridDim.x * 2048u) {
+    const uint2 w = i < n ? *(const uint2*)(P.set_cls + i) : make_uint2(0u, 0u);  // (set_cls is padded to a multiple of 8)
+    uint32_t cls[8];
+#pragma unroll
+    for (uint32_t b = 0; b < 8u; b++) cls[b] = i + b < n ? (((b < 4u ? w.x : w.y) >> (8u * (b & 3u))) & 0xFFu) : 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < 3u; c++) {
+      uint32_t mine = 0;
+#pragma unroll
+      for (uint32_t b = 0; b < 8u; b++) mine += cls[b] == c + 1u ? 1u : 0u;
+      // exclusive prefix of `mine` over the lanes + the wavefront's total
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+        if ((int)(threadIdx.x & 63u) >= o) incl += v;
+      }
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (!total) continue;
+      uint32_t base = 0;
+      if ((threadIdx.x & 63u) == 0) base = atomicAdd(&P.set_count[c], total);
+      base = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+#pragma unroll
+      for (uint32_t b = 0; b < 8u; b++)
+        if (cls[b] == c + 1u) P.set_q[(size_t)c * P.set_cap + base++] = i + b;
+    }
+  }
 }
 
 // ---- the N-sample loops of a (wavefront, light) set ----------------------------------------------------------------------
@@ -329,6 +374,9 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
   const ItemHit it = load_item<L0>(sc, P, item_base + lane, n_items);
   const bool hit = it.hit;
   const lanemask hit_m = wave_ballot(hit);
+  // this wavefront's set ids start out as "no set" (the lane that may overwrite one later: same lane, program order)
+  if (lane == 0)
+    for (uint32_t l = 0; l < sc.n_lights; l++) P.set_cls[(item_base >> 6) * sc.n_lights + l] = 0;
   if (!hit_m) return;
   const Mat m = load_mat(sc, it.sf.mat);
   const bool T = m.transmissive;
@@ -448,8 +496,17 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
   }
   const bool hard_ok = P.hard_q && N > 1 && N <= 64u && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles && P.cand_cap != 0u;
   const uint32_t set_base = (item_base >> 6) * sc.n_lights;
+  // The per-cell candidate lists are a gather from a table of hundreds of megabytes (HBM latency, and the first thing a light's
+  // classification needs): the list of light l + 1 is requested while light l is processed.  (A cell's lists for all lights lie
+  // side by side: mostly the same 64-byte line.)
+  const bool lists_on = !CULL && N > 1 && P.cell_lists && P.cloud_delta > 0.0f && P.traversal == RT_TRAVERSAL_BVH && sc.n_triangles;
+  const uint4 no_list = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  uint4 lst_next = no_list;
+  if (lists_on && hit && cell != RT_NO_CELL) lst_next = P.cell_lists[(size_t)cell * sc.n_lights];
 
   for (uint32_t l = 0; l < sc.n_lights; l++) {
+    const uint4 lst_now = lst_next;
+    if (lists_on && hit && cell != RT_NO_CELL && l + 1u < sc.n_lights) lst_next = P.cell_lists[(size_t)cell * sc.n_lights + l + 1u];
     const float4 L0v = sload<float4>(sc, sc.off_lights + l * 32u);
     // lights below the horizon of the hit point add nothing whatever their shadow rays would find (as process_ray)
     bool use = hit;
@@ -480,8 +537,7 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
       uint32_t pre_reg = 0, pre_count = 0;
       bool have_pre = false;
       if (!CULL && P.cell_lists && walk_tris) {
-        uint4 lst = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (use && cell != RT_NO_CELL) lst = P.cell_lists[(size_t)cell * sc.n_lights + l];
+        const uint4 lst = use ? lst_now : no_list;
         const lanemask unusable = use_m & (wave_ballot(cell == RT_NO_CELL) | wave_ballot((lst.x & 0xFFFFu) == RT_CELL_LIST_OVERFLOW));
         if (!unusable) {
           have_pre = true;

@@ -151,6 +151,7 @@ typedef struct rt_tuning {
 #define RT_PHASES_DEFAULT 0u
 #define RT_PHASES_FUSED 1u
 #define RT_PHASES_SPLIT 2u
+#define RT_PHASES_FUSED_DEFER 3u /* fused kernels; frames without secondary rays also sum through the accumulator and defer incoherent soft-shadow sets to rt_hard_kernel */
 #define RT_TILE_ORDER_DEFAULT 0u
 #define RT_TILE_ORDER_ROW_MAJOR 1u
 #define RT_TILE_ORDER_COST 2u
