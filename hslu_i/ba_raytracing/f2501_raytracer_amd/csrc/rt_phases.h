@@ -381,10 +381,12 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
   const Mat m = load_mat(sc, it.sf.mat);
   const bool T = m.transmissive;
   // ---- the node's own ambient term (part of `direct`, :754; own = transmissive ? spec : direct + spec, :251-257) --------
+  // (what this kernel itself contributes to the lane's pixel -- the ambient term and the shares of the lights whose sets it
+  // finishes inline -- is summed here as integers and added ONCE at the end: a fifth of the atomics, same sum)
+  long long own_x = 0, own_y = 0, own_z = 0;
   {
     const V3 c = it.Wa * ((m.color * mk(1.0f, 1.0f, 1.0f)) * P.ambient);
-    const bool on = hit && !T;
-    add_terms<L0>(P, lds_fx, it, on, __float2ll_rn(c.x * RT_ACC_SCALE), __float2ll_rn(c.y * RT_ACC_SCALE), __float2ll_rn(c.z * RT_ACC_SCALE));
+    if (hit && !T) own_x = __float2ll_rn(c.x * RT_ACC_SCALE), own_y = __float2ll_rn(c.y * RT_ACC_SCALE), own_z = __float2ll_rn(c.z * RT_ACC_SCALE);
     if (L0 && hit) P.acc[4 * (size_t)it.pix + 3] = 1;  // the pixel is written (any sample hit: antialiased_raytrace :1001-1015)
   }
   // ---- children: calculate_reflection :526-729, calculate_refractions :279-524 (as process_ray) ----------------------------
@@ -585,12 +587,13 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
     if (nothing && RT_ARRIVE_INLINE) {
       long long fx, fy, fz;
       set_samples<CULL, SET_ARRIVE>(sc, P, W, it, use_m, l, cand, fx, fy, fz);
-      add_terms<L0>(P, lds_fx, it, lane_of(use_m), fx, fy, fz);
+      if (lane_of(use_m)) own_x += fx, own_y += fy, own_z += fz;
       continue;
     }
     const int cls = nothing ? SET_ARRIVE : ((cand.count != RT_CAND_OVERFLOW && P.traversal != RT_TRAVERSAL_LINEAR && sc.n_triangles) ? SET_LIST : SET_WALK);
     set_write(P, set_base + l, cls, s, cand.reg);
   }
+  add_terms<L0>(P, lds_fx, it, hit, own_x, own_y, own_z);
 }
 
 template <bool CULL, bool L0>
