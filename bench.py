@@ -39,6 +39,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
+# Device memory a scene may spend on its optional acceleration tables (rt_scene_desc.device_budget_bytes).  The library's
+# default is 128 MiB, under which semesterbild keeps its receiver flags (22 MB) but not the per-cell candidate lists (0.86 GB
+# for 2 % of a frame); the bench opts into them and says so (config.scene_budget_bytes, config.scene_memory; the frame time
+# under the library's default budget is reported beside it as `lean_scene`).
+SCENE_BUDGET = 2 << 30
 ALG_BYTES_PER_RAY = 64.0  # 32 B ray in + 32 B hit out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 flop x 2.4 GHz
@@ -177,17 +182,18 @@ def boundary_costs(cfg, flat, lib, _abi, _lib, device):
     from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
 
     t = time.perf_counter()
-    ds = DeviceScene(flat, device=device)
+    ds = DeviceScene(flat, device=device, budget=SCENE_BUDGET)
     scene_create_ms = (time.perf_counter() - t) * 1e3
     p, keep = _abi.make_params(cfg)
     host = np.zeros(cfg.width * cfg.height, np.uint32)
     st = _abi.rt_stats()
-    calls, kern = [], []
+    calls, kern, setup = [], [], []
     for _ in range(4):
         t = time.perf_counter()
         _lib.check(lib.rt_render(ds.handle, C.byref(p), host.ctypes.data, None, C.byref(st)))
         calls.append((time.perf_counter() - t) * 1e3)
         kern.append(st.kernel_ms)
+        setup.append(st.setup_ms)
     t = time.perf_counter()
     fp = flat.fingerprint()
     fingerprint_ms = (time.perf_counter() - t) * 1e3
@@ -196,9 +202,11 @@ def boundary_costs(cfg, flat, lib, _abi, _lib, device):
     return {
         "scene_create_ms": scene_create_ms, "first_call_ms": calls[0], "steady_call_ms": float(np.median(calls[1:])),
         "first_call_device_ms": kern[0], "steady_call_device_ms": float(np.median(kern[1:])),
-        "flags_and_tables_ms": kern[0] - float(np.median(kern[1:])), "fingerprint_ms": fingerprint_ms,
-        "note": "rt_render with a pageable host buffer: H2D of the fill + frame + D2H of the packed pixels; first call adds "
-                "table uploads and rt_flags_kernel (receiver flags, once per scene and light-cloud size)",
+        # rt_stats.setup_ms: device time of what the call enqueues BEFORE its render kernels -- on the first call the sample-table
+        # uploads and rt_flags_kernel with the per-cell lists (once per scene and light-cloud size); kernel_ms never contains it
+        "first_call_setup_ms": setup[0], "steady_call_setup_ms": float(np.median(setup[1:])), "fingerprint_ms": fingerprint_ms,
+        "note": "rt_render with a pageable host buffer: H2D of the fill + frame + D2H of the packed pixels; first_call_setup_ms = "
+                "table uploads + rt_flags_kernel (receiver flags and per-cell candidate lists)",
     }
 
 
@@ -206,7 +214,7 @@ def time_workload(key, lib, _abi, _lib, DeviceScene, torch, dev, device_index, s
     """ms per frame and Mray/s of another workload: `steps` frames back to back through rt_render_device on two streams
     used alternately, HBM-resident frame buffers, wall clock between two synchronisations."""
     cfg, flat, name = build_workload(key)
-    ds = DeviceScene(flat, device=device_index)
+    ds = DeviceScene(flat, device=device_index, budget=SCENE_BUDGET)
     p, keep = _abi.make_params(cfg)
     fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(2)]
     n = [0]  # (the caller's two streams: every further stream would have to share a hardware queue with one of them)
@@ -224,10 +232,18 @@ def time_workload(key, lib, _abi, _lib, DeviceScene, torch, dev, device_index, s
         frame()
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
+    # ... and one frame after the other on ONE stream (what a single frame costs)
+    t0 = time.perf_counter()
+    for _ in range(max(2, steps // 2)):
+        n[0] = 0
+        frame()
+        torch.cuda.synchronize(dev)
+    sec_alone = (time.perf_counter() - t0) / max(2, steps // 2)
     st = _abi.rt_stats()
     _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
     rays = st.rays_primary + st.rays_reflection + st.rays_refraction
     out = {"workload": name, "steps": steps, "frames_in_flight": 2, "ms_per_step": sec * 1e3, "value": rays / sec / 1e6, "unit": "Mray/s",
+           "ms_per_frame_alone": sec_alone * 1e3, "value_alone": rays / sec_alone / 1e6,
            "value_traced": st.rays_traced / sec / 1e6, "mshadow_per_s": st.rays_shadow / sec / 1e6, "rays_per_frame": rays,
            "queue_bytes": int(st.queue_bytes), "notes": int(st.notes)}
     ds.close()
@@ -283,8 +299,8 @@ def main():
     cfg, flat, wname = build_workload(args.workload)
     lib = _lib.load()
     t_scene = time.perf_counter()
-    ds = DeviceScene(flat, device=local_rank)
-    scene_create_ms = (time.perf_counter() - t_scene) * 1e3
+    ds = DeviceScene(flat, device=local_rank, budget=SCENE_BUDGET)
+    first_scene_create_ms = (time.perf_counter() - t_scene) * 1e3  # (the first scene of a process: includes HIP initialisation)
     p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames, phases=args.phases))
     npix = cfg.width * cfg.height
     n_fly = args.in_flight or 2
@@ -373,7 +389,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, own)
     counts = counts.tolist()
-    elapsed, _ = tmax.tolist()
+    elapsed, frame_ms_slowest = tmax.tolist()
     rays = counts[0] + counts[1] + counts[2]
     sec_per_step = elapsed / args.steps
 
@@ -432,6 +448,10 @@ def main():
                        if args.workload == "c3" else "Mray/s (primary+secondary, rays counted as the reference casts them)"),
             "value": mrays, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
+            # `value` / `ms_per_step` are PIPELINED throughput (frames_in_flight frames on alternating streams).  One frame alone on
+            # one stream (device time between HIP events on that stream, mean of the isolated frames after the timed region;
+            # slowest rank at N > 1, gather included):
+            "ms_per_frame_alone": frame_ms_slowest, "value_alone": rays / (frame_ms_slowest * 1e-3) / 1e6,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # the rays the GPU actually traced (bit-identical repeats of the AA sample table are traced once)
             "value_traced": counts[5] / sec_per_step / 1e6,
@@ -445,7 +465,8 @@ def main():
                 "frames_in_flight": n_fly_timed,
                 "bvh": ds.bvh_info(), "build_id": build_id,
                 "notes": int(st.notes), "queue_bytes": int(st.queue_bytes),
-                "scene_create_ms": scene_create_ms,
+                "first_scene_create_ms_incl_hip_init": first_scene_create_ms,
+                "scene_budget_bytes": SCENE_BUDGET, "scene_memory": ds.memory_info(), "phases": args.phases,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -478,6 +499,18 @@ def main():
             out["config"]["mray_per_s_incl_d2h"] = rays / (sec_per_step + out["d2h_ms"] * 1e-3) / 1e6
             if not args.no_boundary_costs:
                 out["boundary"] = boundary_costs(cfg, flat, lib, _abi, _lib, local_rank)
+        if world == 1 and args.workload == "c3" and not args.no_boundary_costs:
+            # the same frame under the library's DEFAULT scene budget (128 MiB: receiver flags, no per-cell candidate lists)
+            lean = DeviceScene(flat, device=local_rank)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+            for a, b in ev:
+                a.record(streams[0])
+                _lib.check(lib.rt_render_device(lean.handle, C.byref(p), C.c_void_p(fbs[0].data_ptr()), None, C.c_void_p(streams[0].cuda_stream)))
+                b.record(streams[0])
+            torch.cuda.synchronize(dev)
+            out["lean_scene"] = {"ms_per_frame_alone": float(np.mean([a.elapsed_time(b) for a, b in ev[2:]])), "scene_memory": lean.memory_info(),
+                                 "note": "rt_scene_desc.device_budget_bytes = 0 (library default)"}
+            lean.close()
         if world == 1 and args.workload == "c3" and not args.no_other_workloads:
             # the other BASELINE configs under the same clock (a few frames each; their own bench lines: --workload c4 / c5)
             out["other_workloads"] = {k: time_workload(k, lib, _abi, _lib, DeviceScene, torch, dev, local_rank, (streams * 2)[:2]) for k in ("c4", "c5")}

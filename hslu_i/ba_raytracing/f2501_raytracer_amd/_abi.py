@@ -14,7 +14,9 @@ RT_CAND_CAP_NONE = 0xFFFFFFFF
 RT_TILE_ORDER_DEFAULT, RT_TILE_ORDER_ROW_MAJOR, RT_TILE_ORDER_COST = 0, 1, 2
 RT_PHASES_DEFAULT, RT_PHASES_FUSED, RT_PHASES_SPLIT, RT_PHASES_FUSED_DEFER = 0, 1, 2, 3
 (RT_NOTE_RECV_FLAGS_OFF_LIGHTS, RT_NOTE_RECV_FLAGS_OFF_CULLING, RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL, RT_NOTE_RECV_FLAGS_OFF_TUNING,
- RT_NOTE_RECV_FLAGS_OFF_SCENE, RT_NOTE_HARD_PAIRS_OFF, RT_NOTE_FRAME_BATCHED, RT_NOTE_CELL_LISTS_OFF) = 1, 2, 4, 8, 16, 32, 64, 128
+ RT_NOTE_RECV_FLAGS_OFF_SCENE, RT_NOTE_HARD_PAIRS_OFF, RT_NOTE_FRAME_BATCHED, RT_NOTE_CELL_LISTS_OFF, RT_NOTE_TILE_ORDER_COST_OFF,
+ RT_NOTE_FRAME_DROPPED_WORK) = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+RT_SCENE_BUDGET_DEFAULT = 128 << 20
 
 _fp = C.POINTER(C.c_float)
 _up = C.POINTER(C.c_uint32)
@@ -42,6 +44,7 @@ class rt_scene_desc(C.Structure):
         ("n_materials", C.c_uint32), ("materials", _fp),
         ("n_lights", C.c_uint32), ("lights", _fp),
         ("bvh", rt_bvh_tuning),
+        ("device_budget_bytes", C.c_uint64),
     ]
 
 
@@ -75,6 +78,7 @@ class rt_stats(C.Structure):
         ("wave_shadow_nodes", C.c_uint64), ("wave_shadow_tris", C.c_uint64), ("wave_shadow_passes", C.c_uint64),
         ("wave_nearest_tris_exact", C.c_uint64), ("wave_shadow_tris_exact", C.c_uint64),
         ("notes", C.c_uint32), ("reserved0", C.c_uint32), ("queue_bytes", C.c_uint64),
+        ("setup_ms", C.c_double), ("scene_bytes", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -102,6 +106,14 @@ class rt_bvh_info(C.Structure):
     ]
 
 
+class rt_scene_info(C.Structure):
+    _fields_ = [
+        ("bytes_geometry", C.c_uint64), ("bytes_bvh", C.c_uint64), ("bytes_flags", C.c_uint64), ("bytes_cell_lists", C.c_uint64),
+        ("bytes_tables", C.c_uint64), ("bytes_workspace", C.c_uint64), ("bytes_frames", C.c_uint64), ("bytes_total", C.c_uint64),
+        ("budget_bytes", C.c_uint64), ("n_receiver_cells", C.c_uint32), ("cell_lists_built", C.c_uint32),
+    ]
+
+
 def fptr(a: np.ndarray):
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(_fp)
@@ -112,8 +124,9 @@ def uptr(a: np.ndarray):
     return a.ctypes.data_as(_up)
 
 
-def make_scene_desc(flat, bvh=None):
-    """flat: FlatScene (contiguous); bvh: dict of rt_bvh_tuning fields.  Returns (desc, keepalive)."""
+def make_scene_desc(flat, bvh=None, budget=0):
+    """flat: FlatScene (contiguous); bvh: dict of rt_bvh_tuning fields; budget: rt_scene_desc.device_budget_bytes (0 = default).
+    Returns (desc, keepalive)."""
     f = flat.contiguous()
     d = rt_scene_desc()
     d.abi_version = RT_ABI_VERSION
@@ -129,6 +142,7 @@ def make_scene_desc(flat, bvh=None):
     d.lights = fptr(f.lights)
     for k, v in (bvh or {}).items():
         setattr(d.bvh, k, v)
+    d.device_budget_bytes = int(budget)
     return d, f
 
 

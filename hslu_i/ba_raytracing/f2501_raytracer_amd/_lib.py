@@ -5,16 +5,16 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._abi import rt_aux, rt_bvh_info, rt_gather_info, rt_params, rt_scene_desc, rt_stats
+from ._abi import rt_aux, rt_bvh_info, rt_gather_info, rt_params, rt_scene_desc, rt_scene_info, rt_stats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_HIP_LIB selects a diagnostic build of the same library (tools/, A/B timing); default: in-tree
 LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 EXPORTS = (
     "rt_device_count", "rt_scene_create", "rt_render", "rt_render_device", "rt_render_collect_stats",
-    "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info", "rt_build_id", "rt_selftest_exact_math",
+    "rt_scene_destroy", "rt_last_error", "rt_scene_bvh_info", "rt_scene_memory_info", "rt_build_id", "rt_selftest_exact_math",
     "rt_gather_layout", "rt_render_multi", "rt_render_multi_begin", "rt_render_multi_end", "rt_multi_release", "rt_comm_unique_id", "rt_comm_create", "rt_comm_destroy",
-    "rt_render_gather_device", "rt_comm_last_gather",
+    "rt_render_gather_device", "rt_comm_last_gather", "rt_render_begin", "rt_render_poll", "rt_render_end",
 )
 
 _lib = None
@@ -53,6 +53,14 @@ def load():
     lib.rt_selftest_exact_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.rt_scene_bvh_info.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(rt_bvh_info)]
+    lib.rt_render_begin.restype = C.c_int
+    lib.rt_render_begin.argtypes = [C.c_void_p, C.POINTER(rt_params), C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.rt_render_poll.restype = C.c_int
+    lib.rt_render_poll.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    lib.rt_render_end.restype = C.c_int
+    lib.rt_render_end.argtypes = [C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_scene_memory_info.restype = C.c_int
+    lib.rt_scene_memory_info.argtypes = [C.c_void_p, C.POINTER(rt_scene_info)]
     u32p = C.POINTER(C.c_uint32)
     lib.rt_gather_layout.restype = C.c_int
     lib.rt_gather_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]

@@ -85,7 +85,7 @@ void rt_scene_destroy(rt_scene* s) {
       for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard, &l.hitrec, &l.sets}) b->release();
     }
   }
-  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags, &s->cell_lists})
+  for (DevBuf* b : {&s->blob, &s->aa, &s->cloud, &s->counters, &s->suplist, &s->fb, &s->aux_rgb, &s->costmap, &s->aux_id, &s->aux_t, &s->flag_geo, &s->flags, &s->cell_lists, &s->progress_fb})
     b->release();
   delete s;
 }
@@ -114,6 +114,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
 
   rt_scene* s = new rt_scene();
   s->device = device;
+  s->budget = d->device_budget_bytes ? d->device_budget_bytes : RT_SCENE_BUDGET_DEFAULT;
   auto bail = [&](int rc) {
     rt_scene_destroy(s);
     return rc;
@@ -267,8 +268,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
           g[8] = e2[0], g[9] = e2[1], g[10] = e2[2], g[11] = 0.f;
           total += (uint64_t)Rr * Rr;
         }
-        if (total <= (1ull << 26)) break;
+        // (the flags -- 2 bytes per cell, plus this kernel input of 48 bytes per triangle -- must fit the scene's budget for optional tables)
+        if (total <= (1ull << 26) && total * 2u + geo.size() * 4u <= s->budget) break;
+        if (total <= nt) break;  // (one cell per triangle: coarser does not exist)
       }
+      // a budget not even the coarsest flags fit: no receiver cells at all (rt_stats.notes: RT_NOTE_RECV_FLAGS_OFF_SCENE)
+      const bool cells_fit = total <= (1ull << 26) && total * 2u + geo.size() * 4u <= s->budget;
+      if (!cells_fit) total = 0;
       put(&s->dev.off_recv, recv.data(), recv.size() * 4);
       s->n_tri_cells = (uint32_t)total;
       {
@@ -277,8 +283,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         for (uint32_t i = 0; i < ns; i++) {
           const double r = std::sqrt(std::fabs((double)d->sphere_r_sq[i]));
           uint32_t Rs = 0;
-          if (std::isfinite(r) && r > 0.0 && cell_used > 0.0) Rs = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(1.5708 * r / cell_used)));
-          if (total + 6ull * Rs * Rs > (1ull << 27)) Rs = 0;
+          if (cells_fit && std::isfinite(r) && r > 0.0 && cell_used > 0.0) Rs = (uint32_t)std::fmin(256.0, std::fmax(1.0, std::ceil(1.5708 * r / cell_used)));
+          if (total + 6ull * Rs * Rs > (1ull << 27) || (total + 6ull * Rs * Rs) * 2u + geo.size() * 4u > s->budget) Rs = 0;
           srecv[2 * i] = Rs, srecv[2 * i + 1] = (uint32_t)total;
           total += 6ull * Rs * Rs;
         }
@@ -386,6 +392,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     put(&s->dev.off_lights, l.data(), l.size() * 4);
   }
   if ((rc = s->counters.ensure(RT_SLOTS * RT_COUNTER_REPLICAS * 16 * sizeof(unsigned long long))) != RT_OK) return bail(rc);
+  s->bytes_bvh = bvh.nodes.size() * sizeof(RtNode) * 9u + (size_t)s->dev.n_thr * sizeof(RtThrNode);
 
   if (blob.size() >= (size_t)1 << 32) return bail(fail(RT_ERR_UNSUPPORTED, "scene data exceeds 4 GiB"));
   if ((rc = upload(s->blob, blob.data(), blob.size())) != RT_OK) return bail(rc);
@@ -410,6 +417,27 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
 int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
   if (!s || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
   *out = s->info;
+  return RT_OK;
+}
+
+int rt_scene_memory_info(const rt_scene* s, rt_scene_info* out) {
+  if (!s || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
+  memset(out, 0, sizeof(*out));
+  out->bytes_bvh = s->bytes_bvh;
+  out->bytes_geometry = s->blob.cap > s->bytes_bvh ? s->blob.cap - s->bytes_bvh : 0;
+  out->bytes_flags = s->flags.cap + s->flag_geo.cap;
+  out->bytes_cell_lists = s->cell_lists.cap;
+  out->bytes_tables = s->aa.cap + s->cloud.cap + s->counters.cap + s->suplist.cap + s->costmap.cap;
+  for (const auto& w : s->ws) {
+    out->bytes_workspace += w.bytes();
+    for (const auto& l : w.lane) out->bytes_workspace += l.qcount.cap;
+  }
+  out->bytes_frames = s->fb.cap + s->aux_rgb.cap + s->aux_id.cap + s->aux_t.cap + s->progress_fb.cap;
+  out->bytes_total = out->bytes_geometry + out->bytes_bvh + out->bytes_flags + out->bytes_cell_lists + out->bytes_tables + out->bytes_workspace +
+                     out->bytes_frames;
+  out->budget_bytes = s->budget;
+  out->n_receiver_cells = s->n_cells;
+  out->cell_lists_built = s->cell_lists_built ? 1u : 0u;
   return RT_OK;
 }
 
@@ -586,12 +614,14 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
         B.cell_list_out = nullptr;
         const size_t list_bytes = (size_t)s->n_cells * s->dev.n_lights * 16u;
         size_t free_b = 0, total_b = 0;
-        if (s->dev.n_slots <= 65533u && hipMemGetInfo(&free_b, &total_b) == hipSuccess && list_bytes <= (free_b + s->cell_lists.cap) / 4 &&
-            s->cell_lists.ensure(list_bytes + 64) == RT_OK) {
+        const size_t flag_bytes = s->flags.cap + s->flag_geo.cap;
+        if (s->dev.n_slots <= 65533u && flag_bytes + list_bytes <= s->budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            list_bytes <= (free_b + s->cell_lists.cap) / 4 && s->cell_lists.ensure(list_bytes + 64) == RT_OK) {
           HIP_TRY(hipMemsetAsync(s->cell_lists.p, 0xFF, list_bytes, stream));
           B.cell_list_out = (uint16_t*)s->cell_lists.p;
           s->cell_lists_built = true;
         }
+        if (!s->cell_lists_built) s->cell_lists.release();  // (a table built under an earlier, larger need)
         hipError_t e = (hipError_t)rt_launch_flags(s->dev, B, stream);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_flags_kernel launch failed: %s", hipGetErrorString(e));
         trace_point(stream, "rt_flags_kernel: cells, lights, lists", s->n_cells, s->dev.n_lights, s->cell_lists_built ? 1u : 0u);
@@ -659,11 +689,13 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   // rank's tiles.  RT_TILE_ORDER_COST: heaviest first, by the cost map measured on a calibration frame of this shape.
   P->sup_list = nullptr;
   P->n_sup = ((P->win_w + 15u) / 16u) * ((P->win_h + 15u) / 16u);
-  const uint32_t order = p->tuning.tile_order == RT_TILE_ORDER_COST ? RT_TILE_ORDER_COST : RT_TILE_ORDER_ROW_MAJOR;
+  uint32_t order = p->tuning.tile_order == RT_TILE_ORDER_COST ? RT_TILE_ORDER_COST : RT_TILE_ORDER_ROW_MAJOR;
+  if (order == RT_TILE_ORDER_COST && !rt_has_cost_kernel()) order = RT_TILE_ORDER_ROW_MAJOR, s->notes |= RT_NOTE_TILE_ORDER_COST_OFF;
   s->cost_wanted = false;
   if (order == RT_TILE_ORDER_COST) {
-    const uint32_t ck[10] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->width, P->height, P->flags, P->aa_rays, P->light_mult,
-                             p->max_depth_reflection | (p->max_depth_refraction << 8) | (p->traversal << 16)};
+    // (the calibration frame times the super-tiles THIS rank owns, and only its primary kernel: secondary levels are not part of the cost)
+    const uint32_t ck[13] = {P->win_x0, P->win_y0, P->win_w, P->win_h, P->width, P->height, P->flags, P->aa_rays, P->light_mult,
+                             p->max_depth_reflection | (p->max_depth_refraction << 8) | (p->traversal << 16), P->n_ranks, P->rank, P->tile_size};
     if (memcmp(ck, s->cost_key, sizeof(ck)) != 0) s->cost_valid = false, memcpy(s->cost_key, ck, sizeof(ck));
     s->cost_wanted = !s->cost_valid;  // the caller runs the calibration frame (calibrate_costs)
   }
@@ -865,6 +897,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   key.split = (split ? 1u : 0u) | (defer ? 2u : 0u), key.sort_bits = s->sort_bits_wanted, key.lists_on = P.cell_lists != nullptr;
   if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
     s->stream_key = key;
+    s->key_gen++;
     s->stream_verified = false;
     s->est_valid = false;
     s->q_cap = s->hard_cap = s->batch_items = 0;
@@ -873,6 +906,23 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   for (auto& o : s->ws)
     if (o.cnt_pending && hipEventQuery(o.cnt_ev) == hipSuccess) {
       o.cnt_pending = false;
+      if (o.cnt_key_gen != s->key_gen) continue;  // (the counts of another frame shape say nothing about this one)
+      // A verified shape renders without waiting for its counters -- but how many pairs a frame defers depends on how its rays
+      // were packed into wavefronts (atomic order in the sort), so a later frame can need a little more than the verified one
+      // did.  If a frame dropped anything, say so (rt_stats.notes) and verify -- i.e. size and, if needed, render again -- the next.
+      bool dropped_any = false;
+      for (uint32_t j = 0; j < o.cnt_host_lanes; j++) {
+        const uint32_t* c = o.cnt_host + (size_t)j * RT_CNT_STRIDE;
+        if (c[RT_CNT_OVERFLOW] || c[RT_CNT_HARD_STAT(o.cnt_host_levels)]) {
+          dropped_any = true;
+          s->hard_cap = std::max<uint32_t>(s->hard_cap, (uint32_t)std::min<uint64_t>((uint64_t)c[RT_CNT_HARD_STAT(o.cnt_host_levels) + 1u] * 5u / 4u + 256u, 0xFFFFFF00ull));
+        }
+      }
+      if (dropped_any) {
+        s->stream_verified = false, s->est_valid = false;
+        s->sticky_notes |= RT_NOTE_FRAME_DROPPED_WORK;
+        continue;
+      }
       if (o.cnt_host_levels == levels && o.cnt_host_lanes == lanes && o.cnt_host_valid) memcpy(s->est, o.cnt_host, sizeof(s->est)), s->est_valid = true;
     }
 
@@ -1130,6 +1180,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       w.cnt_host_levels = levels;
       w.cnt_host_lanes = lanes;
       w.cnt_host_valid = n_batches == lanes;
+      w.cnt_key_gen = s->key_gen;
     }
     if (s->stream_verified && !blocking) return RT_OK;
     HIP_TRY(hipEventSynchronize(w.cnt_ev));
@@ -1144,6 +1195,10 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     if (!dropped && !dropped_pairs) {
       if (w.cnt_host_valid) memcpy(s->est, w.cnt_host, sizeof(s->est)), s->est_valid = true;
       s->stream_verified = true;
+      // headroom for the frames that now run unverified: a quarter more pairs than this frame deferred (takes effect with the next
+      // frame's allocation; nothing was dropped, so this frame stands)
+      if (hard && n_batches == lanes && (uint64_t)need_pairs * 5u / 4u > s->hard_cap)
+        s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)need_pairs * 5u / 4u + 256u, 0xFFFFFF00ull);
       return RT_OK;
     }
     // children or pairs were dropped: the counters say what the frame needed; render it again with that
@@ -1226,8 +1281,11 @@ int rt_collect_stats_slot(rt_scene* s, int slot, rt_stats* st) {
   st->wave_nearest_tris_exact = c[12];
   st->wave_shadow_tris_exact = c[13];
   st->rays_traced = c[14];
-  st->notes = s->notes;
+  st->notes = s->notes | s->sticky_notes;
+  s->sticky_notes = 0;
   st->queue_bytes = s->queue_bytes;
+  rt_scene_info mi;
+  if (rt_scene_memory_info(s, &mi) == RT_OK) st->scene_bytes = mi.bytes_total;
   return RT_OK;
 }
 
@@ -1236,6 +1294,7 @@ extern "C" {
 
 int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux, rt_stats* stats) {
   if (!s || !argb) return fail(RT_ERR_INVALID_ARG, "null argument");
+  if (s->progress_active) return fail(RT_ERR_INVALID_ARG, "a progressive render owns this scene until rt_render_end");
   int rc = rt_validate_params(p);
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(s->device));
@@ -1274,17 +1333,20 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
       ad.hit_t = (float*)s->aux_t.p;
     }
   }
-  EventPair ev;
+  EventPair ev, ev_setup;
   HIP_TRY(hipEventCreate(&ev.e0));
   HIP_TRY(hipEventCreate(&ev.e1));
+  HIP_TRY(hipEventCreate(&ev_setup.e0));
+  HIP_TRY(hipEventRecord(ev_setup.e0, nullptr));  // what prepare enqueues (table uploads, rt_flags_kernel) is timed as setup_ms
   RtDevParams P;
   if ((rc = prepare_ordered(s, p, (uint32_t*)s->fb.p, aux ? &ad : nullptr, nullptr, &P, nullptr, 0)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(ev.e0, nullptr));
   if ((rc = render_frame(s, P, nullptr, p->tuning.chunk_log2, true)) != RT_OK) return rc;
   HIP_TRY(hipEventRecord(ev.e1, nullptr));
   HIP_TRY(hipEventSynchronize(ev.e1));
-  float ms = 0.f;
+  float ms = 0.f, setup_ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  HIP_TRY(hipEventElapsedTime(&setup_ms, ev_setup.e0, ev.e0));
   auto t_copy = std::chrono::steady_clock::now();
   HIP_TRY(copy_window(argb, s->fb.p, 4, hipMemcpyDeviceToHost));
   const double d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copy).count();
@@ -1297,6 +1359,7 @@ int rt_render(rt_scene* s, const rt_params* p, uint32_t* argb, const rt_aux* aux
     memset(stats, 0, sizeof(*stats));
     if ((rc = rt_render_collect_stats(s, stats)) != RT_OK) return rc;
     stats->kernel_ms = ms;
+    stats->setup_ms = setup_ms;
     stats->d2h_ms = d2h_ms;
     stats->total_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -75,6 +75,10 @@ struct rt_scene {
   DevBuf blob;  // spheres, triangles, materials, lights, BVH (RtDevScene offsets)
   // per-render workspaces
   DevBuf aa, cloud, counters, fb, aux_rgb, aux_id, aux_t, suplist;
+  DevBuf progress_fb;   // rt_render_begin: the device frame its bands are rendered into
+  bool progress_active = false;  // a progressive render (rt_render_begin .. rt_render_end) owns the scene
+  uint64_t budget = 0;  // rt_scene_desc.device_budget_bytes as applied: bounds flags + per-cell lists
+  size_t bytes_bvh = 0; // of `blob`: nodes + octant copies + threaded copy
   // What ONE frame with secondary rays owns while it is in flight: ray queues, sort workspace, hard-pair queue, level
   // counters (+ their pinned read-back), pixel accumulator.  Two sets, so that two such frames can be in flight (the
   // second set is only allocated when a frame is enqueued while the one before it is still running).
@@ -96,7 +100,7 @@ struct rt_scene {
     uint32_t* cnt_host = nullptr;     // pinned, [RT_LANES][RT_CNT_STRIDE]: asynchronous read-back of the chains' counters
     hipEvent_t cnt_ev = nullptr, fork_ev = nullptr;
     bool cnt_pending = false, cnt_host_valid = false;
-    uint32_t cnt_host_levels = 0, cnt_host_lanes = 0;
+    uint32_t cnt_host_levels = 0, cnt_host_lanes = 0, cnt_key_gen = 0;
     size_t bytes() const {
       size_t b = acc.cap;
       for (const Lane& l : lane) b += l.queues.cap + l.trace_ws.cap + l.hard.cap + l.hitrec.cap + l.sets.cap;
@@ -108,11 +112,13 @@ struct rt_scene {
   // RT_TILE_ORDER_COST: measured cost per super-tile (window-relative index) for cost_key = frame shape + what a ray costs
   DevBuf costmap;
   std::vector<uint32_t> cost_host;
-  uint32_t cost_key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t cost_key[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool cost_valid = false, cost_wanted = false;
   // ray streaming (frames with secondary rays): sizes shared by both workspace sets, see render_frame_impl
   uint32_t q_cap = 0, hard_cap = 0, batch_items = 0;  // per chain: rays per queue, pairs; primary work items per batch
   StreamKey stream_key{};
+  uint32_t key_gen = 0;          // bumped whenever stream_key changes (counter read-backs are stamped with it)
+  uint32_t sticky_notes = 0;     // notes about frames already delivered (reported by the next rt_render_collect_stats)
   bool stream_verified = false;  // a frame of this key ran without dropping a ray or a pair
   uint32_t est[RT_LANES][RT_CNT_STRIDE] = {{0}};  // the counters of the last complete frame of this key, per chain (grids of the next one)
   bool est_valid = false;

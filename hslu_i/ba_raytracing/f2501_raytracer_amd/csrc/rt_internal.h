@@ -227,6 +227,7 @@ int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, vo
 int rt_launch_classify(const RtDevScene& sc, const RtDevParams& p, bool level0, uint32_t n_wgs, void* stream);
 int rt_launch_compact(const RtDevParams& p, uint32_t n_wgs, void* stream);
 int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int cls, uint32_t n_wgs, void* stream);
+bool rt_has_cost_kernel();       // built with COST=1 (rt_primary_cost_kernel: calibration frames of RT_TILE_ORDER_COST)
 bool rt_phases_arrive_inline();  // this build's K2 finishes ARRIVE sets itself (no ARRIVE launches)
 int rt_launch_selftest_math(const float* in, float* out_sqrt, float* out_rcp, uint32_t n, void* stream);
 // multi-GPU gather, root side (rt_gather.hip): copies the other ranks' staged tiles (recv + rank_off[owner]) into the frame

@@ -1377,7 +1377,8 @@ __device__ __forceinline__ void wave_flush(const Wave& w, const RtDevParams& P, 
 #pragma unroll
     for (unsigned i = 0; i < RT_N_COUNTERS; i++)
       if (v[i]) atomicAdd(&lds_cnt[i], v[i]);
-    before = (uint32_t)atomicAdd(&lds_cnt[15], 1ull);  // (returns after the adds above: LDS serves a wavefront in order)
+    // the hand-off to the wavefront that arrives last: release our sums, acquire everybody else's
+    before = (uint32_t)__hip_atomic_fetch_add(&lds_cnt[15], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   before = __builtin_amdgcn_readfirstlane(before);
   if (before + 1u == (blockDim.x >> 6) && (threadIdx.x & 63u) < RT_N_COUNTERS) {
@@ -2260,7 +2261,14 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(Rt
     primary_body<false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
 }
 
-// calibration frames of RT_TILE_ORDER_COST (once per scene and frame shape): the same kernels + the per-super-tile timers
+// calibration frames of RT_TILE_ORDER_COST (once per scene and frame shape): the same kernels + the per-super-tile timers.
+// Only in builds made with `make COST=1`: the launch order it serves gains nothing once two frames are in flight,
+// and its 354 spilled SGPRs do not belong in the shipped library.  Without it RT_TILE_ORDER_COST renders in row-major order
+// (rt_stats.notes: RT_NOTE_TILE_ORDER_COST_OFF).
+#ifndef RT_COST_KERNEL
+#define RT_COST_KERNEL 0
+#endif
+#if RT_COST_KERNEL
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_cost_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ float4 lds_rgbh[256];
   __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
@@ -2274,6 +2282,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_cost_kernel(RtDe
     else primary_body<false, false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // secondary rays (reflection / refraction children of any depth), three steps per queue chunk:
@@ -2710,6 +2719,7 @@ __global__ __launch_bounds__(256) void rt_selftest_math_kernel(const float* in, 
 }  // namespace
 
 bool rt_phases_arrive_inline() { return RT_ARRIVE_INLINE != 0; }
+bool rt_has_cost_kernel() { return RT_COST_KERNEL != 0; }
 
 int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;
@@ -2778,9 +2788,13 @@ uint32_t rt_primary_total_wgs(const RtDevParams& p) {
 
 int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;  // nothing owned inside the window
-  if (p.cost_map)
+#if RT_COST_KERNEL
+  if (p.cost_map) {
     hipLaunchKernelGGL(rt_primary_cost_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
-  else if (p.acc)
+    return (int)hipGetLastError();
+  }
+#endif
+  if (p.acc)
     hipLaunchKernelGGL(rt_primary_stream_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   else
     hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);

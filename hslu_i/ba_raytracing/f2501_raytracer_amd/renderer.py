@@ -47,9 +47,10 @@ class ImageBuffer:
 class DeviceScene:
     """Owns an `rt_scene*` (device copies + BVH)."""
 
-    def __init__(self, flat: FlatScene, device: int = 0, bvh: Optional[Dict] = None):
+    def __init__(self, flat: FlatScene, device: int = 0, bvh: Optional[Dict] = None, budget: int = 0):
+        """budget: device memory for the optional acceleration tables (rt_scene_desc.device_budget_bytes; 0 = 128 MiB)."""
         lib = _lib.load()
-        desc, keep = _abi.make_scene_desc(flat, bvh)
+        desc, keep = _abi.make_scene_desc(flat, bvh, budget)
         h = C.c_void_p()
         _lib.check(lib.rt_scene_create(C.byref(desc), int(device), C.byref(h)))
         self._h = h
@@ -65,6 +66,11 @@ class DeviceScene:
     def bvh_info(self) -> Dict[str, int]:
         info = _abi.rt_bvh_info()
         _lib.check(_lib.load().rt_scene_bvh_info(self.handle, C.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in info._fields_}
+
+    def memory_info(self) -> Dict[str, int]:
+        info = _abi.rt_scene_info()
+        _lib.check(_lib.load().rt_scene_memory_info(self.handle, C.byref(info)))
         return {k: int(getattr(info, k)) for k, _ in info._fields_}
 
     def close(self):
@@ -86,10 +92,13 @@ class RaytracerRenderer:
     a `RenderConfig` and the renderer caches the device scene between calls.
     """
 
-    def __init__(self, cfg: RenderConfig, device: int = 0, traversal: int = _abi.RT_TRAVERSAL_BVH):
+    def __init__(self, cfg: RenderConfig, device: int = 0, traversal: int = _abi.RT_TRAVERSAL_BVH, scene_budget: int = 0):
+        """scene_budget: rt_scene_desc.device_budget_bytes of the device scenes this renderer creates (0 = the library's
+        default, 128 MiB for the optional acceleration tables)."""
         self.cfg = cfg
         self.device = int(device)
         self.traversal = int(traversal)
+        self.scene_budget = int(scene_budget)
         self._cache: Optional[Tuple[bytes, DeviceScene]] = None
         self.last_stats: Optional[Dict] = None
 
@@ -109,7 +118,7 @@ class RaytracerRenderer:
             return self._cache[1]
         if self._cache is not None:
             self._cache[1].close()
-        ds = DeviceScene(flat, self.device)
+        ds = DeviceScene(flat, self.device, budget=self.scene_budget)
         self._cache = (key, ds)
         return ds
 
@@ -138,21 +147,44 @@ class RaytracerRenderer:
         self.last_stats = st.as_dict()
         return planes
 
-    def render_progressive(self, buffer: ImageBuffer, scene, on_tiles=None, rows_per_step: Optional[int] = None):
-        """Progressive display (reference `Renderer::render` fills the shared u32 buffer tile by tile while the
-        window shows it, renderer/mod.rs:84-209, output/window.rs): the frame is rendered in horizontal bands of
-        `rows_per_step` tile rows (default: one row of RENDER_STRIDE tiles) and `on_tiles(buffer, (x0, y0, w, h))`
-        is called after each band has landed in `buffer`.  The result equals one `render` call (the window
-        parameter of the C ABI renders exactly the pixels inside it).  Returns the number of bands."""
-        cfg = self.cfg
-        ts = cfg.render_stride
-        step = ts * (rows_per_step if rows_per_step else 1)
-        n = 0
-        for y0 in range(0, cfg.height, step):
-            win = (0, y0, cfg.width, min(step, cfg.height - y0))
-            self.render(buffer, scene, window=win)
-            n += 1
-            if on_tiles is not None:
-                on_tiles(buffer, win)
-        return n
+    def render_progressive(self, buffer: ImageBuffer, scene, on_tiles=None, rows_per_step: Optional[int] = None, poll_s: float = 0.0002,
+                           tuning: Optional[Dict] = None):
+        """Progressive display (reference: the render thread fills the shared u32 buffer tile by tile while the window loop
+        keeps showing it, src/main.rs:327-347, renderer/mod.rs:84-209): `rt_render_begin` starts the library's render thread,
+        which renders the frame in bands of `rows_per_step` tile rows (default: one row of RENDER_STRIDE tiles); this thread --
+        the viewer's side -- polls, and `on_tiles(buffer, (x0, y0, w, h))` is called for every band once its rows have landed
+        in `buffer` (rows below are still the caller's fill at that moment).  The final buffer equals one `render` call.
+        Returns the number of bands."""
+        import time
 
+        cfg = self.cfg
+        if buffer.width != cfg.width or buffer.height != cfg.height:
+            raise ValueError(f"buffer is {buffer.width}x{buffer.height}, config renders {cfg.width}x{cfg.height}")
+        step = cfg.render_stride * (rows_per_step if rows_per_step else 1)
+        ds = self.device_scene(scene)
+        p, keep = _abi.make_params(cfg, traversal=self.traversal, tuning=tuning)
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.rt_render_begin(ds.handle, C.byref(p), buffer.buffer.ctypes.data, int(step), C.byref(h)))
+        rows, fin, reported = C.c_uint32(0), C.c_int(0), 0
+        n_bands = -(-cfg.height // step)
+        try:
+            while True:
+                _lib.check(lib.rt_render_poll(h, C.byref(rows), C.byref(fin)))
+                while reported < n_bands and min((reported + 1) * step, cfg.height) <= rows.value:
+                    if on_tiles is not None:
+                        on_tiles(buffer, (0, reported * step, cfg.width, min(step, cfg.height - reported * step)))
+                    reported += 1
+                if fin.value:
+                    break
+                time.sleep(poll_s)
+        finally:
+            st = _abi.rt_stats()
+            rc = lib.rt_render_end(h, C.byref(st))
+        _lib.check(rc)
+        self.last_stats = st.as_dict()
+        while reported < n_bands:  # (bands that landed between the last poll and the end)
+            if on_tiles is not None:
+                on_tiles(buffer, (0, reported * step, cfg.width, min(step, cfg.height - reported * step)))
+            reported += 1
+        return n_bands

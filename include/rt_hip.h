@@ -103,7 +103,15 @@ typedef struct rt_scene_desc {
   const float* lights; /* [n_lights][RT_LIGHT_STRIDE]: x,y,z, r,g,b, intensity */
 
   rt_bvh_tuning bvh; /* all 0 = defaults */
+
+  /* Device memory the scene may spend on OPTIONAL acceleration tables on top of the scene proper (geometry + BVH, a few MB):
+   * the receiver flags (2 bytes per receiver cell) and the per-cell candidate lists (16 bytes per cell and light).  The
+   * reference's whole scene is < 1 MB (src/scene/scene.rs:24-27); a drop-in that shares a device should not quietly take a
+   * gigabyte for a few percent.  0 = RT_SCENE_BUDGET_DEFAULT (128 MiB).  Tables that do not fit are coarsened (flags) or not
+   * built (lists; rt_stats.notes says so) -- the image is the same either way.  rt_scene_memory_info reports what is held. */
+  uint64_t device_budget_bytes;
 } rt_scene_desc;
+#define RT_SCENE_BUDGET_DEFAULT ((uint64_t)128 << 20)
 
 /* Execution knobs that never change the image (no reference counterpart).  All 0 = defaults. */
 #define RT_CAND_CAP_NONE 0xFFFFFFFFu
@@ -247,6 +255,10 @@ typedef struct rt_stats {
   uint32_t notes;
   uint32_t reserved0;
   uint64_t queue_bytes; /* device memory the frame's ray queues, hard-pair queue and sort workspace hold (0 without secondary rays) */
+  /* rt_render: device time between the start of the call's device work and its first render kernel -- sample-table uploads and, on
+   * the first frame that needs them, rt_flags_kernel (receiver flags + per-cell lists).  NOT part of kernel_ms. */
+  double setup_ms;
+  uint64_t scene_bytes; /* device memory the scene handle holds in total right now (rt_scene_memory_info.bytes_total) */
 } rt_stats;
 #define RT_NOTE_RECV_FLAGS_OFF_LIGHTS 0x1u    /* receiver flags need n_lights <= 8 */
 #define RT_NOTE_RECV_FLAGS_OFF_CULLING 0x2u   /* ... and no backface culling */
@@ -255,7 +267,10 @@ typedef struct rt_stats {
 #define RT_NOTE_RECV_FLAGS_OFF_SCENE 0x10u    /* no receiver cells (no triangles / degenerate scene) or no light cloud */
 #define RT_NOTE_HARD_PAIRS_OFF 0x20u          /* incoherent soft-shadow sets are traced inline (light_mult > 64, linear, cap) */
 #define RT_NOTE_FRAME_BATCHED 0x40u           /* the ray queues did not fit: the frame ran in several primary batches */
-#define RT_NOTE_CELL_LISTS_OFF 0x80u          /* no per-cell candidate lists (receiver flags off, > 65 533 leaf slots, no memory, tuning) */
+#define RT_NOTE_CELL_LISTS_OFF 0x80u          /* no per-cell candidate lists (receiver flags off, > 65 533 leaf slots, over the scene's budget, tuning) */
+#define RT_NOTE_TILE_ORDER_COST_OFF 0x100u    /* RT_TILE_ORDER_COST asked for, library built without the calibration kernel (make COST=1): row-major */
+#define RT_NOTE_FRAME_DROPPED_WORK 0x200u     /* an asynchronously rendered frame of this shape overflowed a ray / pair queue (its counters came back
+                                                 later): some of its secondary terms are missing; the queues have grown and the next frame is verified */
 
 typedef struct rt_scene rt_scene; /* opaque: device copies + BVH */
 
@@ -330,6 +345,23 @@ int rt_render_collect_stats(rt_scene* scene, rt_stats* stats);
 
 void rt_scene_destroy(rt_scene* scene);
 
+/* ---- progressive read-back: the frame lands in the caller's buffer band by band WHILE it is being rendered ----------------
+ *
+ * Reference: main() spawns a thread that calls render(&buffer, &scene) and meanwhile blits the same buffer in its window loop
+ * (src/main.rs:327-347); the buffer is [AtomicU32], written tile by tile with relaxed stores and read with relaxed loads
+ * (src/image_buffer.rs:39-44,243-250).  Here `begin` starts the library's own render thread: the frame (or params' window) is
+ * rendered in bands of `band_rows` rows (0 = tile_size, one row of RENDER_STRIDE tiles: renderer/mod.rs:84-90) on a stream of
+ * its own, every finished band is copied to pinned host memory, and a counter says how many rows have landed.  `poll` -- the
+ * UI thread's side; it never blocks -- copies the rows that are new since the last poll into `argb` and reports the count; rows
+ * [win_y0, win_y0 + rows_done) of `argb` are then final, the rows below still hold the caller's fill.  `end` waits for the
+ * rest, hands it over and frees the handle; its stats are summed over the bands.  `argb` (HOST, W*H, pre-filled by the caller)
+ * must stay valid until `end`; params and its tables are copied by `begin`.  One progressive render per scene at a time, and no
+ * other render call on that scene until `end`.  The final buffer equals rt_render's. */
+typedef struct rt_progress rt_progress;
+int rt_render_begin(rt_scene* scene, const rt_params* params, uint32_t* argb, uint32_t band_rows, rt_progress** out);
+int rt_render_poll(rt_progress* progress, uint32_t* rows_done, int* finished);
+int rt_render_end(rt_progress* progress, rt_stats* stats);
+
 /* thread-local message for the last non-RT_OK return on this thread */
 const char* rt_last_error(void);
 
@@ -352,6 +384,22 @@ typedef struct rt_bvh_info {
   uint32_t n_references; /* triangle references in the leaves (>= n_triangles: split clipping) */
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
+
+/* What a scene handle holds in device memory, by purpose (the reference's Scene: src/scene/scene.rs:24-27, < 1 MB of host memory). */
+typedef struct rt_scene_info {
+  uint64_t bytes_geometry;    /* spheres, triangle records (intersection + shading), ids, materials, lights, receiver records */
+  uint64_t bytes_bvh;         /* BVH nodes + the 8 per-octant copies + the threaded copy */
+  uint64_t bytes_flags;       /* receiver flags + the cell geometry rt_flags_kernel reads (optional table, under the budget) */
+  uint64_t bytes_cell_lists;  /* per-cell candidate lists (optional table, under the budget; 0 = not built) */
+  uint64_t bytes_tables;      /* AA samples, light clouds, tile lists, counters */
+  uint64_t bytes_workspace;   /* ray queues, sort workspace, pair queues, set records, pixel accumulators of every frame slot in use */
+  uint64_t bytes_frames;      /* frame buffer + aux planes rt_render keeps for host callers */
+  uint64_t bytes_total;
+  uint64_t budget_bytes;      /* rt_scene_desc.device_budget_bytes as applied (bounds bytes_flags + bytes_cell_lists) */
+  uint32_t n_receiver_cells;
+  uint32_t cell_lists_built;  /* 1 = the lists exist (they are built by the first frame with soft shadows) */
+} rt_scene_info;
+int rt_scene_memory_info(const rt_scene* scene, rt_scene_info* out);
 
 /* ---- multi-GPU: tile-partitioned frame + ONE gather of the packed pixels to rank 0 (RCCL over xGMI) ---------
  *

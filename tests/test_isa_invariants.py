@@ -19,16 +19,23 @@ ASM = os.path.join(CSRC, "rt_kernels.s")
 ALLOWED = {
     "rt_primary_kernel": 0,
     "rt_primary_stream_kernel": 0,
-    "rt_primary_cost_kernel": 0,
     "rt_shade_kernel": 0,
     "rt_trace_kernel": 0,
     "rt_hard_kernel": 1,   # the stackless per-lane walk of incoherent (hit point, light) pairs: divergent by design
     "rt_flags_kernel": 1,  # the per-lane binary search for the triangle that owns a receiver cell
+    # the phase-split pipeline (rt_phases.h)
+    "rt_hit_kernel": 0,
+    "rt_classify0_kernel": 0,
+    "rt_classify_kernel": 0,
+    "rt_sets0_list_kernel": 0,
+    "rt_sets_list_kernel": 0,
+    "rt_sets0_walk_kernel": 0,
+    "rt_sets_walk_kernel": 0,
 }
 
 
 def _asm_text():
-    srcs = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_internal.h", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_phases.h", "rt_internal.h", "Makefile")]
     if not os.path.exists(ASM) or os.path.getmtime(ASM) < max(os.path.getmtime(f) for f in srcs):
         if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
             pytest.skip("no hipcc")
@@ -53,11 +60,12 @@ def test_render_kernels_have_no_divergent_loops():
 
 def test_walks_fetch_their_nodes_through_scalar_loads():
     bodies = _kernel_bodies(_asm_text())
-    for name in ("rt_primary_kernel", "rt_primary_stream_kernel", "rt_shade_kernel", "rt_trace_kernel", "rt_flags_kernel"):
+    for name in ("rt_primary_kernel", "rt_primary_stream_kernel", "rt_shade_kernel", "rt_trace_kernel", "rt_flags_kernel", "rt_hit_kernel",
+                 "rt_classify0_kernel", "rt_classify_kernel"):
         assert "s_load_dwordx16" in bodies[name], f"{name}: no 64-byte scalar node fetch (a walk lost its uniformity)"
 
 
 def test_lane_indexed_stores_ignore_exec():
     bodies = _kernel_bodies(_asm_text())
-    for name in ("rt_primary_kernel", "rt_shade_kernel", "rt_trace_kernel", "rt_flags_kernel"):
+    for name in ("rt_primary_kernel", "rt_shade_kernel", "rt_trace_kernel", "rt_flags_kernel", "rt_hit_kernel", "rt_classify0_kernel", "rt_classify_kernel"):
         assert "v_writelane_b32" in bodies[name], name

@@ -68,3 +68,54 @@ def test_oracle_tile_partition_union():
         assert not ((acc != 0) & (part != 0)).any()
         acc |= part
     assert np.array_equal(acc, full)
+
+
+# ---- the at-spec fixtures (tests/golden/spec_*.npz, made offline by tests/golden/make_spec_golden.py with the threaded packet
+# restatement): a corner of every fixture's first window is rendered again with the SCALAR oracle and must be the same bits ----
+import make_spec_golden  # noqa: E402
+
+SPEC_CASES = sorted(n for n in make_spec_golden.SPEC_CASES if os.path.exists(os.path.join(HERE, "golden", n + ".npz")))
+
+
+def check_spec_window(z, i, win, cfg, argb, planes, stats, rgb_tol, sub=None, want_stats=None):
+    """`sub` = (dx, dy, w, h) inside the fixture's window `win`: compare only that part."""
+    dx, dy, w, h = sub if sub else (0, 0, win[2], win[3])
+    region = (win[0] + dx, win[1] + dy, w, h)
+    sl = (slice(dy, dy + h), slice(dx, dx + w))
+    g_id, g_t = make_spec_golden.crop(cfg, region, planes["hit_id"]), make_spec_golden.crop(cfg, region, planes["hit_t"])
+    g_rgb, g_argb = make_spec_golden.crop(cfg, region, planes["rgb"]), make_spec_golden.crop(cfg, region, argb)
+    f_id, f_t, f_rgb, f_argb = z[f"w{i}_hit_id"][sl], z[f"w{i}_hit_t"][sl], z[f"w{i}_rgb"][sl], z[f"w{i}_argb"][sl]
+    assert np.array_equal(g_id, f_id), f"{int((g_id != f_id).sum())} hit ids differ"
+    assert np.array_equal(g_argb != 0, f_argb != 0)
+    hit = f_id >= 0
+    assert np.array_equal(g_t[hit].view(np.uint32), f_t[hit].view(np.uint32)), "hit t not bit-exact"
+    d = float(np.abs(g_rgb - f_rgb).max())
+    assert d <= rgb_tol, d
+    for sh in (24, 16, 8, 0):
+        assert np.abs(((g_argb >> sh) & 0xFF).astype(np.int32) - ((f_argb >> sh) & 0xFF).astype(np.int32)).max() <= 1
+    if want_stats is not None:
+        for k, v in want_stats.items():
+            assert stats[k] == v, (k, stats[k], v)
+    return d
+
+
+@pytest.mark.parametrize("name", SPEC_CASES)
+def test_scalar_oracle_reproduces_a_corner_of_every_at_spec_fixture(name):
+    import bench
+    meta, z = make_spec_golden.load(name)
+    cfg, flat, _ = bench.build_workload(meta["workload"])
+    assert (cfg.width, cfg.height) == (meta["width"], meta["height"])
+    win = meta["windows"][0]
+    sub = (win[2] // 2 - 3, win[3] // 2 - 2, 6, 4)  # 24 pixels in the middle of the first window (the sphere's rim)
+    region = (win[0] + sub[0], win[1] + sub[1], sub[2], sub[3])
+    argb, planes, st = oracle_lib.render(flat, cfg, window=region)
+    check_spec_window(z, 0, win, cfg, argb, planes, st, rgb_tol=2e-6, sub=sub)
+
+
+def test_at_spec_fixtures_cover_every_baseline_config_with_3000_pixels():
+    for name in ("spec_c3", "spec_c3lowres", "spec_c4", "spec_c4d21", "spec_c5"):
+        meta, z = make_spec_golden.load(name)
+        assert sum(w[2] * w[3] for w in meta["windows"]) >= 3000, name
+        for i, w in enumerate(meta["windows"]):
+            assert z[f"w{i}_hit_id"].shape == (w[3], w[2]) and z[f"w{i}_rgb"].shape == (w[3], w[2], 3)
+            assert (z[f"w{i}_hit_id"] >= 0).any()

@@ -28,11 +28,11 @@ def window_mask(cfg, win):
     return m.ravel()
 
 
-def gpu_render(cfg, flat, win=None, traversal=_abi.RT_TRAVERSAL_BVH, n_ranks=1, rank=0, aux=True, **tuning):
+def gpu_render(cfg, flat, win=None, traversal=_abi.RT_TRAVERSAL_BVH, n_ranks=1, rank=0, aux=True, budget=0, **tuning):
     """One render through the C ABI.  tuning: rt_tuning fields -- shadow_candidate_cap (shared soft-shadow candidate
     cap; RT_CAND_CAP_NONE = a BVH walk per sample), chunk_log2 (rays per secondary launch), no_aa_dedup."""
     buf = ImageBuffer.new(cfg.width, cfg.height)
-    r = RaytracerRenderer(cfg, device=0, traversal=traversal)
+    r = RaytracerRenderer(cfg, device=0, traversal=traversal, scene_budget=budget)
     planes = r.render(buf, flat, window=win, aux=aux, n_ranks=n_ranks, rank=rank, tuning=tuning)
     return buf.buffer.copy(), planes, r.last_stats
 
@@ -1440,11 +1440,96 @@ def test_per_cell_candidate_lists_give_the_walks_candidates():
     cfg_s = RenderConfig.from_features(["high_resolution", "anti_aliasing", "soft_shadows"], n_cloud_sets=64)
     cases.append((cfg_s, scenes.semesterbild(cfg_s, "text").flatten(), (380, 330, 420, 300)))
     for c, flat, win in cases:
-        a0, p0, s0 = gpu_render(c, flat, win)
-        a1, p1, s1 = gpu_render(c, flat, win, no_cell_lists=1)
+        # (semesterbild's lists are 0.86 GB: over the default budget of a scene, rt_scene_desc.device_budget_bytes -- opt in)
+        a0, p0, s0 = gpu_render(c, flat, win, budget=2 << 30)
+        a1, p1, s1 = gpu_render(c, flat, win, budget=2 << 30, no_cell_lists=1)
         assert not s0["notes"] & _abi.RT_NOTE_CELL_LISTS_OFF and s1["notes"] & _abi.RT_NOTE_CELL_LISTS_OFF
         assert np.array_equal(a0, a1) and np.array_equal(p0["rgb"].view(np.uint32), p1["rgb"].view(np.uint32))
         assert np.array_equal(p0["hit_id"], p1["hit_id"])
         for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written"):
             assert s0[k] == s1[k], k
         assert (a0 != 0).any()
+
+
+def test_progressive_poll_sees_tiles_land_while_the_frame_is_still_rendering():
+    """rt_render_begin / rt_render_poll / rt_render_end (the reference's UI thread reads the buffer while the render
+    thread fills it, src/main.rs:327-347): a viewer thread that polls sees a PARTIAL frame -- the rows reported done are final,
+    the rows below still hold the caller's fill -- and ends with the buffer one rt_render call gives."""
+    import ctypes as C
+    import time
+
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    cfg, flat, _ = bench.build_workload("c4")
+    lib = _lib.load()
+    ds = DeviceScene(flat, 0)
+    p, keep = _abi.make_params(cfg)
+    W, H = cfg.width, cfg.height
+    ref = np.zeros(W * H, np.uint32)
+    st_ref = _abi.rt_stats()
+    _lib.check(lib.rt_render(ds.handle, C.byref(p), ref.ctypes.data, None, C.byref(st_ref)))
+    fill = 0x00010203
+    buf = np.full(W * H, fill, np.uint32)
+    h = C.c_void_p()
+    _lib.check(lib.rt_render_begin(ds.handle, C.byref(p), buf.ctypes.data, 0, C.byref(h)))
+    # the scene is owned by the progressive render until rt_render_end
+    h2 = C.c_void_p()
+    assert lib.rt_render_begin(ds.handle, C.byref(p), buf.ctypes.data, 0, C.byref(h2)) == _abi.RT_ERR_INVALID_ARG
+    assert lib.rt_render(ds.handle, C.byref(p), ref.copy().ctypes.data, None, None) == _abi.RT_ERR_INVALID_ARG
+    rows, fin = C.c_uint32(0), C.c_int(0)
+    partial = []
+    while True:
+        _lib.check(lib.rt_render_poll(h, C.byref(rows), C.byref(fin)))
+        r = int(rows.value)
+        if 0 < r < H and not fin.value:
+            done, todo = buf[: r * W], buf[r * W:]
+            partial.append((r, bool(np.array_equal(done, np.where(ref[: r * W] != 0, ref[: r * W], fill))), bool((todo == fill).all())))
+        if fin.value:
+            break
+        time.sleep(0.0005)
+    st = _abi.rt_stats()
+    _lib.check(lib.rt_render_end(h, C.byref(st)))
+    assert partial, "no poll saw a partial frame"
+    assert all(ok and untouched for _, ok, untouched in partial), partial[:4]
+    assert len({r for r, _, _ in partial}) >= 2 and all(r % cfg.render_stride == 0 for r, _, _ in partial)
+    assert np.array_equal(buf, np.where(ref != 0, ref, fill))
+    for k in ("rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "pixels_written", "rays_traced"):
+        assert getattr(st, k) == getattr(st_ref, k), k
+    # the handle is gone: the scene renders normally again
+    again = np.zeros(W * H, np.uint32)
+    _lib.check(lib.rt_render(ds.handle, C.byref(p), again.ctypes.data, None, None))
+    assert np.array_equal(again, ref)
+    ds.close()
+    print(f"progressive: {len(partial)} polls saw a partial frame (rows {partial[0][0]} .. {partial[-1][0]} of {H}); {st.total_ms:.1f} ms")
+
+
+def test_scene_memory_info_and_budget():
+    """rt_scene_memory_info / rt_scene_desc.device_budget_bytes: under the default budget (128 MiB) semesterbild's scene holds
+    its receiver flags but not the 0.86 GB of per-cell candidate lists (rt_stats.notes says so); a caller that opts in gets them;
+    the frame is the same bits either way."""
+    import ctypes as C
+
+    from hslu_i.ba_raytracing.f2501_raytracer_amd import _lib
+    from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene
+    cfg, flat, _ = bench.build_workload("c3")
+    lib = _lib.load()
+    p, keep = _abi.make_params(cfg, window=(300, 300, 640, 480))
+    frames, infos, notes = [], [], []
+    for budget in (0, 2 << 30, 1 << 20):
+        ds = DeviceScene(flat, 0, budget=budget)
+        buf = np.zeros(cfg.width * cfg.height, np.uint32)
+        st = _abi.rt_stats()
+        _lib.check(lib.rt_render(ds.handle, C.byref(p), buf.ctypes.data, None, C.byref(st)))
+        info = ds.memory_info()
+        assert st.scene_bytes == info["bytes_total"] and st.setup_ms > 0.0
+        frames.append(buf), infos.append(info), notes.append(int(st.notes))
+        ds.close()
+    lean, rich, tiny = infos
+    assert lean["budget_bytes"] == _abi.RT_SCENE_BUDGET_DEFAULT and lean["bytes_cell_lists"] == 0 and lean["cell_lists_built"] == 0
+    assert lean["bytes_flags"] + lean["bytes_cell_lists"] <= lean["budget_bytes"] and lean["bytes_flags"] > 0
+    assert lean["bytes_geometry"] + lean["bytes_bvh"] < 16 << 20
+    assert notes[0] & _abi.RT_NOTE_CELL_LISTS_OFF and not (notes[1] & _abi.RT_NOTE_CELL_LISTS_OFF)
+    assert rich["cell_lists_built"] == 1 and rich["bytes_cell_lists"] > 500 << 20
+    assert tiny["bytes_flags"] + tiny["bytes_cell_lists"] <= 1 << 20
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    print({k: round(v / 1e6, 1) for k, v in lean.items() if k.startswith("bytes")}, {k: round(v / 1e6, 1) for k, v in rich.items() if k.startswith("bytes")})

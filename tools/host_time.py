@@ -35,7 +35,7 @@ args = ap.parse_args()
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 cfg, flat, _ = bench.build_workload(args.workload)
-ds = DeviceScene(flat, 0)
+ds = DeviceScene(flat, 0, budget=int(os.environ.get('RT_AB_BUDGET_MB', '2048')) << 20)  # (like bench.py: the per-cell lists are opted into)
 NS = [int(v) for v in args.streams.split(",")]
 TUNING = {k: int(v, 0) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)}
 fbs = [torch.zeros(cfg.width * cfg.height, dtype=torch.int32, device=dev) for _ in range(max(NS))]

@@ -47,7 +47,7 @@ for spec in args or ["c3"]:
         flat = dataclasses.replace(flat, lights=flat.lights[: int(os.environ["RT_AB_LIGHTS"])])
     # RT_AB_BVH="max_leaf=8,tri_cost=1.0": rt_bvh_tuning fields
     bvh = {k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in os.environ.get("RT_AB_BVH", "").split(",") if kv)}
-    ds = DeviceScene(flat, 0, bvh=bvh)
+    ds = DeviceScene(flat, 0, bvh=bvh, budget=int(os.environ.get('RT_AB_BUDGET_MB', '2048')) << 20)  # (like bench.py)
     # RT_AB_TUNING="no_aa_dedup=1,chunk_log2=20": rt_tuning fields
     tuning = {k: int(v, 0) for k, v in (kv.split("=") for kv in os.environ.get("RT_AB_TUNING", "").split(",") if kv)}
     p, keep = _abi.make_params(cfg, window=window, n_ranks=n_ranks, rank=rank, tuning=tuning)
