@@ -12,17 +12,50 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 import test_parity_gpu as T  # noqa: E402
 from hslu_i.ba_raytracing.f2501_raytracer_amd import RenderConfig, _abi, _lib  # noqa: E402
 from hslu_i.ba_raytracing.f2501_raytracer_amd.renderer import DeviceScene  # noqa: E402
 
 
 
+class Hip:
+    """Device buffers and streams straight from the HIP runtime librt_hip.so is linked against (dlsym on the library's handle
+    searches its dependency tree; importing torch AFTER the library would map a second, mismatching runtime)."""
+
+    def __init__(self, lib):
+        self.h = lib
+
+    def ok(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def zeros(self, n_words):
+        p = C.c_void_p()
+        self.ok(self.h.hipMalloc(C.byref(p), C.c_size_t(n_words * 4)))
+        self.ok(self.h.hipMemset(p, 0, C.c_size_t(n_words * 4)))
+        self.ok(self.h.hipDeviceSynchronize())
+        return p
+
+    def fetch(self, p, n_words):
+        out = np.zeros(n_words, np.int32)
+        self.ok(self.h.hipMemcpy(C.c_void_p(out.ctypes.data), p, C.c_size_t(n_words * 4), 2))
+        return out
+
+    def free(self, p):
+        self.ok(self.h.hipFree(p))
+
+    def stream(self):
+        sp = C.c_void_p()
+        self.ok(self.h.hipStreamCreateWithFlags(C.byref(sp), 1))  # hipStreamNonBlocking
+        return sp
+
+    def sync(self, stream=None):
+        self.ok(self.h.hipDeviceSynchronize() if stream is None else self.h.hipStreamSynchronize(stream))
+
+
 def run(first, last):
     """Seeds first..last; returns the number of failures."""
     lib = _lib.load()
-    dev = torch.device("cuda", 0)
+    hip = Hip(lib)
     FEATS = [["realistic", "anti_aliasing", "soft_shadows"], ["anti_aliasing", "high_quality"], ["soft_shadows", "reflections"], ["realistic"],
              ["anti_aliasing", "soft_shadows", "refractions"], [], ["anti_aliasing"], ["realistic", "soft_shadows"]]
     bad = 0
@@ -58,16 +91,18 @@ def run(first, last):
             p, keep = _abi.make_params(cfg, window=win, n_ranks=n_ranks, rank=rank, tuning=tuning)
             # reference: a fresh scene handle, this frame alone
             ds0 = DeviceScene(flat, 0)
-            fb = torch.zeros(W * H, dtype=torch.int32, device=dev)
-            _lib.check(lib.rt_render_device(ds0.handle, C.byref(p), C.c_void_p(fb.data_ptr()), None, None))
-            torch.cuda.synchronize()
+            fb = hip.zeros(W * H)
+            _lib.check(lib.rt_render_device(ds0.handle, C.byref(p), fb, None, None))
+            hip.sync()
             st = _abi.rt_stats()
             _lib.check(lib.rt_render_collect_stats(ds0.handle, C.byref(st)))
             ds0.close()
-            sets.append(dict(p=p, keep=keep, ref=fb.cpu().numpy().copy(), rays=(st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow),
+            ref = hip.fetch(fb, W * H)
+            hip.free(fb)
+            sets.append(dict(p=p, keep=keep, ref=ref, rays=(st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow),
                              what=f"{feats} win {win} ranks {n_ranks}/{rank} {tuning}"))
         ds = DeviceScene(flat, 0)
-        streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        streams = [None] + [hip.stream() for _ in range(3)]
         pending = []  # (set index, buffer)
         n_frames = int(r.integers(20, 60))
         log = []
@@ -76,15 +111,13 @@ def run(first, last):
             if r.random() < 0.5 and log:
                 i = log[-1][0]  # runs of the same shape (the verified, unsynchronised path) are the common case
             j = int(r.integers(0, len(streams)))
-            fb = torch.zeros(W * H, dtype=torch.int32, device=dev)
-            torch.cuda.current_stream().synchronize()  # (the zero fill runs on torch's stream)
-            sp = C.c_void_p(streams[j].cuda_stream) if streams[j] is not None else None
-            _lib.check(lib.rt_render_device(ds.handle, C.byref(sets[i]["p"]), C.c_void_p(fb.data_ptr()), None, sp))
+            fb = hip.zeros(W * H)  # (synchronises: the zero fill is complete)
+            _lib.check(lib.rt_render_device(ds.handle, C.byref(sets[i]["p"]), fb, None, streams[j]))
             pending.append((i, fb))
             log.append((i, j))
             u = r.random()
             if u < 0.15:
-                torch.cuda.synchronize()
+                hip.sync()
                 st = _abi.rt_stats()
                 _lib.check(lib.rt_render_collect_stats(ds.handle, C.byref(st)))
                 got = (st.rays_primary, st.rays_reflection, st.rays_refraction, st.rays_shadow)
@@ -92,14 +125,19 @@ def run(first, last):
                     bad += 1
                     print(f"seed {seed} frame {f}: counters {got} != {sets[i]['rays']} for {sets[i]['what']}; sequence {log}")
             elif u < 0.25 and streams[j] is not None:
-                streams[j].synchronize()
-        torch.cuda.synchronize()
+                hip.sync(streams[j])
+        hip.sync()
         for f, (i, fb) in enumerate(pending):
-            if not np.array_equal(fb.cpu().numpy(), sets[i]["ref"]):
+            got = hip.fetch(fb, W * H)
+            if not np.array_equal(got, sets[i]["ref"]):
                 bad += 1
-                print(f"seed {seed} frame {f}: {int((fb.cpu().numpy() != sets[i]['ref']).sum())} pixels differ for {sets[i]['what']}; sequence {log}")
+                print(f"seed {seed} frame {f}: {int((got != sets[i]['ref']).sum())} pixels differ for {sets[i]['what']}; sequence {log}")
                 break
+        for _, fb in pending:
+            hip.free(fb)
         ds.close()
+        for sp in streams[1:]:
+            hip.ok(lib.hipStreamDestroy(sp))
         print(f"seed {seed}: {n_frames} frames of {len(sets)} shapes " + ("ok" if not bad else f"({bad} failures so far)"))
     print(f"{bad} failures in seeds {first}..{last}")
     return bad
