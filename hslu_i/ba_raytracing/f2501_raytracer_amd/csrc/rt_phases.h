@@ -343,9 +343,20 @@ __device__ __forceinline__ void set_samples(const RtDevScene& sc, const RtDevPar
       const V3 ld = ltp * exact_rcp(mag(ltp));  // normalize(ltp): the shadow ray's geometry is exact
       const V3 so = it.sf.p + ld * epsv;
       const float tmax = mag(lp - so);
+#if RT_SKIP  // removal ablations (timing / instruction counts only, wrong image): 1 no sphere tests, 2 no triangle tests, 32 no lighting
+      CandList cand_ab = cand;
+      if (RT_SKIP & 1) cand_ab.spheres = 0;
+      if (RT_SKIP & 2) cand_ab.count = 0;
+      const Shadow S = shadow_ray<CULL, CLS == SET_LIST>(sc, P, W, use_m, so, ld, tmax, cand_ab);
+#else
       const Shadow S = shadow_ray<CULL, CLS == SET_LIST>(sc, P, W, use_m, so, ld, tmax, cand);
+#endif
       const lanemask reach_m = use_m & ~S.occ;
       if (!reach_m) continue;
+      if (RT_SKIP & 32) {  // (keeps the shadow result live)
+        if (lane_of(reach_m)) dl.x += (float)S.dec + (float)S.fr, ds.x += tmax;
+        continue;
+      }
       const LightTerms T = light_sample_terms<true>(it.sf.n, it.d, mmc_lc, lI, m.shininess, has_spec, ltp, S);
       if (lane_of(reach_m) && T.lit) {
         dl = fma_s(T.mLc, T.lf, dl);
