@@ -133,6 +133,35 @@ int main(void) {
     rt_scene_destroy(three[2]);
     free(multi);
   }
+  /* the reference's window loop shows the buffer WHILE the render thread fills it (src/main.rs:327-347): begin / poll / end */
+  {
+    uint32_t* prog = (uint32_t*)calloc((size_t)p.width * p.height, 4);
+    rt_progress* h = NULL;
+    if (rt_render_begin(scene, &p, prog, 16 /* rows per band */, &h) != RT_OK) {
+      fprintf(stderr, "rt_render_begin: %s\n", rt_last_error());
+      return 1;
+    }
+    uint32_t rows = 0, polls = 0;
+    int finished = 0;
+    while (!finished) {
+      if (rt_render_poll(h, &rows, &finished) != RT_OK) return 1; /* never blocks: rows [0, rows) of prog are final */
+      polls++;
+    }
+    rt_stats sp;
+    if (rt_render_end(h, &sp) != RT_OK) {
+      fprintf(stderr, "rt_render_end: %s\n", rt_last_error());
+      return 1;
+    }
+    const int bad3 = memcmp(prog, argb, (size_t)p.width * p.height * 4) != 0 || sp.pixels_written != st.pixels_written || rows != p.height;
+    printf("rt_render_begin/_poll/_end: %u polls, progressive frame %s rt_render\n", polls, bad3 ? "DIFFERS from" : "matches");
+    bad |= bad3;
+    free(prog);
+    rt_scene_info mi;
+    if (rt_scene_memory_info(scene, &mi) != RT_OK) return 1;
+    printf("scene holds %llu bytes on the device (geometry %llu, BVH %llu, optional tables %llu of a budget of %llu)\n",
+           (unsigned long long)mi.bytes_total, (unsigned long long)mi.bytes_geometry, (unsigned long long)mi.bytes_bvh,
+           (unsigned long long)(mi.bytes_flags + mi.bytes_cell_lists), (unsigned long long)mi.budget_bytes);
+  }
   rt_scene_destroy(scene);
   free(argb);
   /* pixels whose ray misses everything keep the caller's background, as in the reference */

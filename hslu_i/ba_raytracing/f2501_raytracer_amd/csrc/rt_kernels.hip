@@ -765,6 +765,9 @@ struct CandList {
   uint32_t count;   // uniform; RT_CAND_OVERFLOW = not usable, walk the BVH per sample instead
   uint32_t spheres; // uniform bit mask: sphere i (< 32) may be touched by some sample ray of some lane
   unsigned long long umbra;  // uniform lane mask: every sample ray of the lane certainly hits one opaque triangle
+#if RT_PROFILE == 5
+  uint32_t own;  // per lane: candidates of the list that survive THIS lane's own beam test (the others are only another lane's)
+#endif
 };
 
 // Receiver flags (rt_flags_kernel, RtDevParams::recv_flags): the collection also runs ONCE PER SCENE over the cells of
@@ -802,6 +805,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
   L.count = 0;
   L.spheres = 0xFFFFFFFFu;
   L.umbra = 0ull;
+#if RT_PROFILE == 5
+  L.own = 0;
+#endif
   const uint32_t lane_id = threadIdx.x & 63u;
   // parametric segment x(s) = p + s*(c - p), s in [0, 1]
   V3 dseg = c - p;
@@ -937,6 +943,9 @@ __device__ __forceinline__ CandList collect_light_candidates(const RtDevScene& s
                               wave_ballot(dlo * rcp_lenp > __builtin_fmaf(2e-6f, X1, 2e-7f));
       L.umbra |= lanes & ~open & inside;
     }
+#if RT_PROFILE == 5
+    if (lane_of(lanes & (open | ~rej))) L.own++;
+#endif
     return false;
   };
   const unsigned long long grp = wave_ballot(alive);
@@ -1761,6 +1770,18 @@ __device__ __forceinline__ RayOut process_ray(const RtDevScene& sc, const RtDevP
       continue;
     }
     const bool nothing = cand.count == 0 && cand.spheres == 0;  // wave-uniform
+#if RT_PROFILE == 5  // what lane regrouping could save in the sets that are traced with a shared list
+    if (!nothing && cand.count != RT_CAND_OVERFLOW && N > 1) {
+      const uint32_t nl = (uint32_t)__popcll(use_m);
+      W.prof[0] += 1;                                   // LIST sets
+      W.prof[1] += nl;                                  // lanes in them
+      W.prof[2] += nl * cand.count;                     // (lane, candidate) pairs the sample loops test: every lane against the whole list
+      W.prof[3] += wave_sum(use ? cand.own : 0u);       // ... pairs that survive the lane's OWN beam test
+      W.prof[4] += (uint32_t)__popcll(use_m & wave_ballot(cand.own != 0u));   // lanes with a candidate of their own
+      W.prof[5] += (uint32_t)__popc(cand.spheres & ((1u << (sc.n_spheres < 32u ? sc.n_spheres : 31u)) - 1u)) * nl;  // (lane, sphere) pairs
+      W.prof[6] += cand.count;                          // list lengths
+    }
+#endif
 #if RT_PROFILE == 4  // how full the wavefronts are in each class of (wavefront, light) set (what lane compaction could gain)
     {
       const uint32_t nl = (uint32_t)__popcll(use_m);

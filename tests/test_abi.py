@@ -109,3 +109,4 @@ def test_c_example_renders_on_the_gpu(tmp_path):
     assert "two frames in flight match rt_render" in out.stdout and "3 ranks on one GPU match" in out.stdout
     # the multi-GPU entry point with n_gpu = 1 and with 3 tile-partitioned ranks rehearsed on the one GPU
     assert "rt_render_multi: 1 GPU and 3 ranks on one GPU match rt_render" in out.stdout
+    assert "progressive frame matches rt_render" in out.stdout and "scene holds" in out.stdout

@@ -81,6 +81,13 @@ for spec in args or ["c3"]:
         print(f"{'':28s} sets with nothing to test: {n_no} ({l_no/max(1,n_no):.1f} lanes each) | sets traced: {n_tr} "
               f"({l_tr/max(1,n_tr):.1f} lanes each) | candidates by BVH walk: {walked} sets, by per-cell lists: {listed} sets "
               f"({pre/max(1,listed):.1f} slots per union)")
+    elif os.environ.get("RT_HIP_LIB", "").endswith("_prof5.so"):
+        # make PROFILE=5 build: what regrouping lanes could save in the sets that are traced with a shared candidate list
+        sets, lanes, pairs, own, needy, sph, lens = (st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris,
+                                                     st.wave_nearest_tris_exact, st.wave_shadow_tris_exact, st.wave_ray_lanes)
+        print(f"{'':28s} LIST sets {sets}: {lanes/max(1,sets):.1f} lanes, list length {lens/max(1,sets):.2f}; (lane, candidate) pairs tested per sample "
+              f"{pairs} -> surviving the lane's own beam {own} ({100.0*own/max(1,pairs):.1f} %); lanes with a candidate of their own "
+              f"{needy} of {lanes} ({100.0*needy/max(1,lanes):.1f} %); (lane, sphere) pairs {sph}")
     elif os.environ.get("RT_HIP_LIB", "").endswith("_prof3.so"):
         # make PROFILE=3 build: outcome of the candidate sets that had something to test
         h = [st.wave_nearest_nodes, st.wave_nearest_tris, st.wave_shadow_nodes, st.wave_shadow_tris, st.wave_nearest_tris_exact,
