@@ -167,7 +167,10 @@ def cpu_baseline(cfg, flat, budget_s=18.0):
                   f"be built offline)",
         "build": build,
         "mshadow_per_s": st["rays_shadow"] / dt / 1e6,
-        "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mray/s", "sample": f"8 px at the frame centre, {dt1:.2f} s"},
+        "per_core": rays / dt / 1e6 / cores,
+        # (only sizes the sample above: 8 adjacent pixels where every ray hits -- NOT comparable with the spread sample, so no
+        # parallel-efficiency figure is derived from it)
+        "sizing_probe_one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mray/s", "sample": f"8 px at the frame centre, {dt1:.2f} s"},
         "cpu_model": cpu_info(), "cpus_visible": os.cpu_count(), "cpus_granted": cores,
     }
 
