@@ -271,6 +271,9 @@ def main():
                          "no other frame of the scene is running, one otherwise); profiles use 1 (chains stretch each other's launches)")
     ap.add_argument("--phases", type=int, default=0, choices=[0, 1, 2],
                     help="rt_tuning.phases: 0 = the library's choice, 1 = fused kernels, 2 = phase-split pipeline (csrc/rt_phases.h)")
+    ap.add_argument("--levels", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="rt_tuning.levels: 0 = the library's choice, 1 = trace/sort/shade per level, 2 = all levels traced first + one shade "
+                         "launch, 3 = levels traced back to back, each shaded on one of two streams as soon as it is sorted")
     ap.add_argument("--backend", default=os.environ.get("RT_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path); gloo only to rehearse N > 1 on a one-GPU box")
     args = ap.parse_args()
@@ -304,7 +307,7 @@ def main():
     t_scene = time.perf_counter()
     ds = DeviceScene(flat, device=local_rank, budget=SCENE_BUDGET)
     first_scene_create_ms = (time.perf_counter() - t_scene) * 1e3  # (the first scene of a process: includes HIP initialisation)
-    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames, phases=args.phases))
+    p, keep = _abi.make_params(cfg, n_ranks=world, rank=rank, tuning=dict(sub_frames=args.sub_frames, phases=args.phases, levels=args.levels))
     npix = cfg.width * cfg.height
     n_fly = args.in_flight or 2
     if args.backend == "gloo" and world > 1:

@@ -13,6 +13,7 @@ RT_TRAVERSAL_BVH, RT_TRAVERSAL_LINEAR = 0, 1
 RT_CAND_CAP_NONE = 0xFFFFFFFF
 RT_TILE_ORDER_DEFAULT, RT_TILE_ORDER_ROW_MAJOR, RT_TILE_ORDER_COST = 0, 1, 2
 RT_PHASES_DEFAULT, RT_PHASES_FUSED, RT_PHASES_SPLIT, RT_PHASES_FUSED_DEFER = 0, 1, 2, 3
+RT_LEVELS_DEFAULT, RT_LEVELS_CHAINED, RT_LEVELS_MERGED, RT_LEVELS_PIPELINED = 0, 1, 2, 3
 (RT_NOTE_RECV_FLAGS_OFF_LIGHTS, RT_NOTE_RECV_FLAGS_OFF_CULLING, RT_NOTE_RECV_FLAGS_OFF_TRAVERSAL, RT_NOTE_RECV_FLAGS_OFF_TUNING,
  RT_NOTE_RECV_FLAGS_OFF_SCENE, RT_NOTE_HARD_PAIRS_OFF, RT_NOTE_FRAME_BATCHED, RT_NOTE_CELL_LISTS_OFF, RT_NOTE_TILE_ORDER_COST_OFF,
  RT_NOTE_FRAME_DROPPED_WORK) = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
@@ -31,7 +32,7 @@ class rt_tuning(C.Structure):
     _fields_ = [("shadow_candidate_cap", C.c_uint32), ("chunk_log2", C.c_uint32), ("no_aa_dedup", C.c_uint32),
                 ("no_counters", C.c_uint32), ("multi_force_rccl", C.c_uint32), ("no_receiver_flags", C.c_uint32),
                 ("tile_order", C.c_uint32), ("sort_bits", C.c_uint32), ("no_cell_lists", C.c_uint32),
-                ("sub_frames", C.c_uint32), ("phases", C.c_uint32)]
+                ("sub_frames", C.c_uint32), ("phases", C.c_uint32), ("levels", C.c_uint32)]
 
 
 class rt_scene_desc(C.Structure):

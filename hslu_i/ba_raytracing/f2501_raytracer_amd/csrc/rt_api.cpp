@@ -82,6 +82,11 @@ void rt_scene_destroy(rt_scene* s) {
     for (auto& l : w.lane) {
       if (l.stream) (void)hipStreamSynchronize(l.stream), (void)hipStreamDestroy(l.stream);
       if (l.done_ev) (void)hipEventDestroy(l.done_ev);
+      for (int k = 0; k < 2; k++) {
+        if (l.shade_stream[k]) (void)hipStreamSynchronize(l.shade_stream[k]), (void)hipStreamDestroy(l.shade_stream[k]);
+        if (l.shade_done[k]) (void)hipEventDestroy(l.shade_done[k]);
+      }
+      for (hipEvent_t e : l.level_ev) (void)hipEventDestroy(e);
       for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard, &l.hitrec, &l.sets}) b->release();
     }
   }
@@ -467,6 +472,7 @@ int rt_validate_params(const rt_params* p) {
   if (p->tuning.sort_bits && (p->tuning.sort_bits < 12u || p->tuning.sort_bits > 24u))
     return fail(RT_ERR_INVALID_ARG, "tuning.sort_bits outside 12..24");
   if (p->tuning.sub_frames > RT_LANES) return fail(RT_ERR_INVALID_ARG, "tuning.sub_frames > %u", (unsigned)RT_LANES);
+  if (p->tuning.levels > RT_LEVELS_PIPELINED) return fail(RT_ERR_INVALID_ARG, "tuning.levels > %u", (unsigned)RT_LEVELS_PIPELINED);
   if (p->tuning.phases > RT_PHASES_FUSED_DEFER) return fail(RT_ERR_INVALID_ARG, "tuning.phases > %u", (unsigned)RT_PHASES_FUSED_DEFER);
   return RT_OK;
 }
@@ -637,6 +643,7 @@ static int prepare(rt_scene* s, const rt_params* p, uint32_t* argb_dev, const rt
   s->sort_bits_wanted = p->tuning.sort_bits;
   s->lanes_wanted = p->tuning.sub_frames;
   s->phases_wanted = p->tuning.phases;
+  s->levels_wanted = p->tuning.levels;
   if (p->win_w) {
     P->win_x0 = p->win_x0, P->win_y0 = p->win_y0, P->win_w = p->win_w, P->win_h = p->win_h;
   } else {
@@ -760,7 +767,8 @@ static const size_t RT_QUEUE_BUDGET = (size_t)160 << 30;  // hard ceiling; the r
 #define RT_CNT_HARD_STAT(levels) ((levels) + 3u) // [0] dropped pairs, [1] largest batch of pairs
 #define RT_CNT_HITS(levels, k) ((levels) + 5u + (k))  // rays of level k that hit something
 #define RT_CNT_SETS(levels, k, c) (2u * (levels) + 8u + 3u * (k) + (c))  // phase-split pipeline: sets of class c at level k = 0 .. levels
-#define RT_CNT_TOTAL(levels) (2u * (levels) + 8u + 3u * ((levels) + 1u))
+#define RT_CNT_SEG(levels, k) (2u * (levels) + 8u + 3u * ((levels) + 1u) + (k))  // merged levels: first queue index of level k = 1 .. levels + 1
+#define RT_CNT_TOTAL(levels) (2u * (levels) + 8u + 3u * ((levels) + 1u) + (levels) + 2u)
 
 // Diagnostics: RT_TRACE_LAUNCHES=1 in the environment makes every launch of a frame wait for its kernel and report it on
 // stderr (which launch of which level does not come back, with which sizes); never set in timed runs.
@@ -787,6 +795,14 @@ static uint32_t grid_for(uint64_t items, uint32_t per_wg, uint32_t cap_wgs) {
 }
 
 static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, uint32_t forced_chunk_log2, bool blocking);
+
+// how the levels of a ray tree are run (rt_tuning.levels)
+// (measured, round 4: MERGED config 4 40.6 ms alone / 39.3 with two frames in flight against 49.8 / 42.6 CHAINED, config 5 120.4 / 118.4
+// against 126.4 / 122.3; PIPELINED 47.7 / 42.9 and 129.4 / 123.3: one hit-point order over all levels is worth more than the overlap)
+static uint32_t rt_levels_mode(uint32_t wanted) {
+  if (wanted == RT_LEVELS_DEFAULT) return RT_LEVELS_MERGED;
+  return wanted;
+}
 
 // which form of the render loop a frame takes (rt_tuning.phases; RT_PHASES_DEFAULT: by frame shape)
 static bool rt_use_phases(uint32_t wanted, const RtDevParams& P, bool secondary) {
@@ -837,6 +853,10 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   // Soft-shadow sets of incoherent wavefronts are deferred to rt_hard_kernel as (hit point, light) pairs
   const bool hard = (secondary || split || defer) && P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
+  // merged levels (rt_tuning.levels): every level traced first (the trace kernel appends the children), then ONE sort and ONE shade launch
+  const uint32_t levels_mode = (secondary && !split) ? rt_levels_mode(s->levels_wanted) : RT_LEVELS_CHAINED;
+  const bool pipelined = levels_mode == RT_LEVELS_PIPELINED;
+  const bool merged = levels_mode == RT_LEVELS_MERGED || pipelined;  // (one append-only queue per chain, children spawned by the trace kernel)
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);
   // ---- chains.  The ray tree of a frame is a chain of launches, one per level, each with a drain of its own (a launch
   // cannot end before its longest wavefront does).  A frame that has the GPU to itself is therefore split into two
@@ -854,7 +874,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     s->calm_frames = busy ? 0u : std::min<uint32_t>(s->calm_frames + 1u, 1u << 30);
     if (s->calm_frames < 8u) lanes = 1;
   }
-  if (forced_chunk_log2 || items < (1ull << 16) || (!secondary && !s->lanes_wanted)) lanes = 1;  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
+  if (forced_chunk_log2 || items < (1ull << 16) || (!secondary && !s->lanes_wanted)) lanes = 1;
+  if (merged && !s->lanes_wanted) lanes = 1;  // (measured: two chains add nothing once the levels share one shade launch)  // (forced batch sizes: the batching itself is under test; tiny frames: nothing to overlap)
   // This frame's workspace set: the one of its slot -- unless that would mean ALLOCATING a second set on a device that
   // cannot spare the memory (a partitioned or shared GPU): then the frame waits for the frame that uses set 0 and takes it.
   int wsi = s->cur_block;
@@ -894,6 +915,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   key.tables = s->tables_version;
   memcpy(key.f, P.focus, 12), key.f[3] = P.fw, key.f[4] = P.fh, key.f[5] = P.fd, key.f[6] = P.eps_distance, key.f[7] = P.air_ior;
   key.staged = P.stage_slot != nullptr, key.flags_on = P.recv_flags != nullptr, key.n_sup = P.n_sup, key.lanes = lanes;
+  key.merged = levels_mode;
   key.split = (split ? 1u : 0u) | (defer ? 2u : 0u), key.sort_bits = s->sort_bits_wanted, key.lists_on = P.cell_lists != nullptr;
   if (memcmp(&key, &s->stream_key, sizeof(key)) != 0) {
     s->stream_key = key;
@@ -932,9 +954,14 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     rt_scene::StreamWs& w;
     uint32_t lanes;
     bool forked = false, joined = false;
+    bool shading = false;  // pipelined levels: work is in flight on the chains' shade streams
     ~Joiner() {
       if (forked && !joined)
         for (uint32_t j = 1; j < lanes; j++) (void)hipStreamSynchronize(w.lane[j].stream);
+      if (shading)
+        for (uint32_t j = 0; j < lanes; j++)
+          for (int k = 0; k < 2; k++)
+            if (w.lane[j].shade_stream[k]) (void)hipStreamSynchronize(w.lane[j].shade_stream[k]);
     }
   } joiner{w, lanes};
 
@@ -948,7 +975,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       } else {
         const uint64_t lane_items = ((uint64_t)total_wgs + lanes - 1u) / lanes * 256u;
         s->batch_items = (uint32_t)std::min<uint64_t>(lane_items, 1ull << 28);
-        s->q_cap = s->batch_items;
+        // (merged levels: ONE queue of 2 q_cap rays holds every level of the tree -- three times the primary work items as a first guess)
+        s->q_cap = merged ? (uint32_t)std::min<uint64_t>((uint64_t)s->batch_items * 3u / 2u, 0x7FFFFF00ull) : s->batch_items;
       }
       if (s->q_cap < (1u << 16)) s->q_cap = 1u << 16;
       s->hard_cap = hard ? std::max<uint32_t>(s->q_cap / 8u, 1u << 16) : 0u;
@@ -960,7 +988,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     // set id: 32-byte header, 64-dword candidate list, a slot in each of the three class queues)
     auto set_cap_for = [&](uint64_t q, uint64_t batch) { return (uint32_t)(((std::max<uint64_t>(levels ? q : 0u, batch + 64u * 256u) / 64u + 4u) * std::max<uint32_t>(s->dev.n_lights, 1u) + 15u) & ~7ull); };
     auto bytes_for = [&](uint64_t q, uint64_t h) {
-      size_t b = levels ? (size_t)(q * (2u * 64u + 12u) + (h ? (h + 64u) * 64u : 0u)) : 0u;
+      size_t b = levels ? (size_t)(q * (2u * 64u + (merged ? 24u : 12u)) + (h ? (h + 64u) * 64u : 0u)) : 0u;
       if (split) b += (size_t)(s->batch_items + 64u * 256u) * 8u + (size_t)set_cap_for(q, s->batch_items) * (32u + 256u + 12u + 1u);
       return (size_t)lanes * b;
     };
@@ -977,12 +1005,14 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     P.sort_bits = s->sort_bits_wanted ? s->sort_bits_wanted : (items >= (32ull << 20) ? RT_SORT_BITS_DEFAULT + 2u : RT_SORT_BITS_DEFAULT);
     const uint32_t n_buckets = 1u << P.sort_bits;
     rc = RT_OK;
+    // (merged levels: the two queues of q_cap rays are ONE queue of 2 q_cap -- same memory -- and the sort workspace covers all of it)
+    const uint32_t q_sort_cap = merged ? 2u * s->q_cap : s->q_cap;
     const uint32_t set_cap = split ? set_cap_for(s->q_cap, s->batch_items) : 0u;
     const size_t hitrec_items = (size_t)s->batch_items + 64u * 256u;  // (an interleaved chain's launch is rounded up to whole groups)
     for (uint32_t j = 0; j < lanes && rc == RT_OK; j++) {
       if (levels) {
         rc = w.lane[j].queues.ensure((size_t)2 * s->q_cap * RT_QUEUE_QUADS * sizeof(float4));
-        if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)s->q_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
+        if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)q_sort_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
       }
       if (rc == RT_OK && hard) rc = w.lane[j].hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
       if (rc == RT_OK && split) rc = w.lane[j].hitrec.ensure(hitrec_items * 8u);
@@ -1001,7 +1031,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     }
     const uint32_t n_batches = (uint32_t)((items + s->batch_items - 1) / s->batch_items);
     if (n_batches > lanes) s->notes |= RT_NOTE_FRAME_BATCHED;
-    const uint32_t cap_wgs = (s->q_cap + 255u) / 256u;
+    const uint32_t cap_wgs = (q_sort_cap + 255u) / 256u;
     const bool guess = s->est_valid && n_batches == lanes;  // grids from the previous frame's counts (else: whole capacity)
     const uint32_t ppw = 64u / (P.light_mult < 2u ? 2u : P.light_mult), pairs_per_wg = 4u * (ppw ? ppw : 1u);
     const uint32_t hard_cap_wgs = hard ? (s->hard_cap + pairs_per_wg - 1u) / pairs_per_wg : 1u;
@@ -1016,8 +1046,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       Q = P;
       uint32_t* ws = (uint32_t*)L.trace_ws.p;
       Q.sort_slot = (uint2*)ws;  // (8-byte aligned: first)
-      Q.sh_idx = ws + (size_t)2 * s->q_cap;
-      Q.sort_hist = Q.sh_idx + s->q_cap;
+      Q.sh_idx = ws + (size_t)2 * q_sort_cap;
+      Q.sort_hist = Q.sh_idx + q_sort_cap;
       Q.sort_offs = Q.sort_hist + n_buckets;
       Q.sort_tile = Q.sort_offs + n_buckets;
       if (split) {
@@ -1087,6 +1117,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       Q.q_in = nullptr, Q.q_in_count = nullptr;
       Q.q_out = levels ? q[j][0] : nullptr;
       Q.q_out_count = counts[j] + RT_CNT_LEVEL(1);
+      Q.q_capacity = q_sort_cap;  // (merged levels: the chain's two queues are one, and RT_CNT_LEVEL(1) is its running total)
+      Q.seg_lo = Q.seg_hi = nullptr;
       hipError_t e;
       // the (wavefront, light) sets K2 queued for level k, one launch per class (grids: last frame's counts of this shape)
       auto run_sets = [&](uint32_t k, uint32_t n_sets_host) -> int {
@@ -1122,7 +1154,77 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         trace_point(st, "rt_primary_stream_kernel: first workgroup, workgroups, queue capacity", w0, nw, s->q_cap);
       }
-      for (uint32_t k = 1; k <= levels; k++) {
+      if (merged) {
+        // ---- every level traced first: rt_trace_spawn_kernel finds the hits of the slice [seg[k], seg[k + 1]) of the chain's ONE queue and
+        // appends their children behind it; the slice's end is a stream-ordered snapshot of the queue's running total
+        if ((rc = run_hard(j, st)) != RT_OK) return rc;  // the pairs the primary launch deferred
+        rt_scene::Lane& L = w.lane[j];
+        uint32_t* total = counts[j] + RT_CNT_LEVEL(1);
+        if (lane_batches[j] > 1) HIP_TRY(hipMemsetAsync(counts[j] + RT_CNT_SEG(levels, 0), 0, (size_t)(levels + 2u) * 4, st));
+        if (pipelined) {
+          for (int k = 0; k < 2; k++) {
+            if (!L.shade_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&L.shade_stream[k], hipStreamNonBlocking));
+            if (!L.shade_done[k]) HIP_TRY(hipEventCreateWithFlags(&L.shade_done[k], hipEventDisableTiming));
+          }
+          while (L.level_ev.size() < levels) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            L.level_ev.push_back(ev);
+          }
+        }
+        Q.q_in = q[j][0];
+        Q.q_out = q[j][0];
+        Q.q_out_count = total;
+        Q.q_in_count = total;
+        for (uint32_t k = 1; k <= levels; k++) {
+          HIP_TRY(hipMemcpyAsync(counts[j] + RT_CNT_SEG(levels, k + 1u), total, 4, hipMemcpyDeviceToDevice, st));
+          Q.seg_lo = counts[j] + RT_CNT_SEG(levels, k);
+          Q.seg_hi = counts[j] + RT_CNT_SEG(levels, k + 1u);
+          Q.q_out = q[j][0], Q.q_out_count = total;
+          const uint32_t n_k = guess ? s->est[j][RT_CNT_SEG(levels, k + 1u)] - s->est[j][RT_CNT_SEG(levels, k)] : 0u;
+          const uint32_t g_rays = guess ? grid_for(n_k, 256u, cap_wgs) : cap_wgs;
+          e = (hipError_t)rt_launch_trace(s->dev, Q, g_rays, st);
+          if (e != hipSuccess) return fail(RT_ERR_HIP, "trace launch failed: %s", hipGetErrorString(e));
+          trace_point(st, "rt_trace_spawn_kernel: level, workgroups, chain", k, g_rays, j);
+          if (pipelined) {
+            // the level's own hit-point order (its slice of sh_idx), then its shading on one of the chain's two shade streams: the
+            // next levels are traced meanwhile, and the head of level k + 1's shading fills the drain of level k's
+            Q.sort_hits = counts[j] + RT_CNT_HITS(levels, k);
+            e = (hipError_t)rt_launch_sort(Q, g_rays, st);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(L.level_ev[k - 1u], st));
+            hipStream_t ss = L.shade_stream[k & 1u];
+            HIP_TRY(hipStreamWaitEvent(ss, L.level_ev[k - 1u], 0));
+            joiner.shading = true;
+            RtDevParams S = Q;
+            S.q_out = nullptr, S.q_out_count = nullptr;  // (the children exist already)
+            const uint32_t g_hits = guess ? grid_for(s->est[j][RT_CNT_HITS(levels, k)], 256u, cap_wgs) : cap_wgs;
+            e = (hipError_t)rt_launch_shade(s->dev, S, g_hits, ss);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+            trace_point(ss, "rt_shade_kernel: level, workgroups, chain (pipelined)", k, g_hits, j);
+          }
+        }
+        Q.seg_lo = Q.seg_hi = nullptr;
+        Q.q_out = nullptr, Q.q_out_count = nullptr;
+        if (pipelined) {
+          for (int k = 0; k < 2; k++) {  // join: the pairs the shade launches deferred, and the resolve, need all of them
+            HIP_TRY(hipEventRecord(L.shade_done[k], L.shade_stream[k]));
+            HIP_TRY(hipStreamWaitEvent(st, L.shade_done[k], 0));
+          }
+          joiner.shading = false;  // (joined on the device: the chain's stream now orders everything behind the shade launches)
+        } else {
+          // ---- MERGED: one hit-point order over the rays of all levels, one shade launch (no children: they exist already)
+          Q.sort_hits = counts[j] + RT_CNT_HITS(levels, 1);
+          const uint32_t g_all = guess ? grid_for(s->est[j][RT_CNT_LEVEL(1)], 256u, cap_wgs) : cap_wgs;
+          const uint32_t g_hits = guess ? grid_for(s->est[j][RT_CNT_HITS(levels, 1)], 256u, cap_wgs) : cap_wgs;
+          e = (hipError_t)rt_launch_sort(Q, g_all, st);
+          if (e != hipSuccess) return fail(RT_ERR_HIP, "sort launch failed: %s", hipGetErrorString(e));
+          e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
+          if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
+          trace_point(st, "rt_shade_kernel (all levels): workgroups, chain", g_hits, j);
+        }
+      }
+      for (uint32_t k = 1; k <= levels && !merged; k++) {
         if ((rc = run_hard(j, st)) != RT_OK) return rc;  // the pairs the launch before deferred
         Q.q_in = q[j][(k - 1u) & 1u];
         Q.q_in_count = counts[j] + RT_CNT_LEVEL(k);
@@ -1189,7 +1291,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
     for (uint32_t j = 0; j < lanes; j++) {
       const uint32_t* c = w.cnt_host + (size_t)j * RT_CNT_STRIDE;
       dropped += c[RT_CNT_OVERFLOW], dropped_pairs += c[RT_CNT_HARD_STAT(levels)];
-      for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, c[RT_CNT_LEVEL(k)]);
+      // (merged levels: RT_CNT_LEVEL(1) is the running total of ONE queue of 2 q_cap rays)
+      for (uint32_t k = 1; k <= levels + 1u; k++) need = std::max(need, merged ? (c[RT_CNT_LEVEL(k)] + 1u) / 2u : c[RT_CNT_LEVEL(k)]);
       need_pairs = std::max(need_pairs, c[RT_CNT_HARD_STAT(levels) + 1u]);
     }
     if (!dropped && !dropped_pairs) {
@@ -1202,8 +1305,10 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       return RT_OK;
     }
     // children or pairs were dropped: the counters say what the frame needed; render it again with that
-    if (attempt >= 6) return fail(RT_ERR_HIP, "%u child rays / %u pair batches were dropped (queues could not be sized)", dropped, dropped_pairs);
+    if (attempt >= (merged ? 12 : 6)) return fail(RT_ERR_HIP, "%u child rays / %u pair batches were dropped (queues could not be sized)", dropped, dropped_pairs);
     if (n_batches == lanes && !forced_chunk_log2) {
+      // (one queue for all levels: the rays that were dropped would have had children of their own, so the count is a lower bound)
+      if (merged && dropped) need = std::max<uint32_t>(need + need / 4u, s->q_cap + s->q_cap / 2u);
       if (need > s->q_cap) s->q_cap = (uint32_t)std::min<uint64_t>((uint64_t)need + need / 16u + 256u, 0xFFFFFF00ull);
       if (need_pairs > s->hard_cap) s->hard_cap = (uint32_t)std::min<uint64_t>((uint64_t)need_pairs + need_pairs / 8u + 256u, 0xFFFFFF00ull);
     } else {

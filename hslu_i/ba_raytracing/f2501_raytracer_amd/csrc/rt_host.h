@@ -64,7 +64,7 @@ struct EventPair {  // destroyed on every return path
 // verified frame renders without a synchronisation
 struct StreamKey {
   uint32_t width, height, flags, aa_rays, aa_unique, light_mult, depth_refl, depth_refr, win[4], tile_size, n_ranks, rank, traversal,
-      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup, lanes, split, sort_bits, lists_on;
+      cand_cap, cloud_seed, n_cloud_sets, forced, tables, staged, flags_on, n_sup, lanes, split, sort_bits, lists_on, merged;
   float f[8];
 };
 
@@ -92,6 +92,10 @@ struct rt_scene {
     uint32_t sort_hist_buckets = 0;
     hipStream_t stream = nullptr;     // chains 1..: their own stream
     hipEvent_t done_ev = nullptr;     // ... and the event the caller's stream waits for before the resolve
+    // pipelined levels (rt_tuning.levels): the two streams levels are shaded on alternately, their join events, one event per traced level
+    hipStream_t shade_stream[2] = {nullptr, nullptr};
+    hipEvent_t shade_done[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> level_ev;
   };
   struct StreamWs {
     Lane lane[RT_LANES];
@@ -125,6 +129,7 @@ struct rt_scene {
   uint32_t sort_bits_wanted = 0;    // rt_tuning.sort_bits of the current frame (0 = default)
   uint32_t lanes_wanted = 0;        // rt_tuning.sub_frames of the current frame (0 = default)
   uint32_t phases_wanted = 0;       // rt_tuning.phases of the current frame (0 = default)
+  uint32_t levels_wanted = 0;       // rt_tuning.levels of the current frame (0 = default)
   uint32_t calm_frames = 1u << 30;  // frames enqueued in a row while no other frame of the scene was running (sub_frames = 0: auto)
   uint32_t tables_version = 0;      // bumped whenever a parameter table (AA samples, light clouds, flags, tile list) is uploaded
   float aabb_lo[3] = {0.f, 0.f, 0.f}, aabb_hi[3] = {1.f, 1.f, 1.f};  // bounds of all objects (Morton keys)

@@ -198,6 +198,9 @@ struct RtDevParams {
   uint32_t set_cap;     // set ids are (first item / 64) * n_lights + light < set_cap: a class queue cannot overflow
   uint32_t set_items;   // level 0: work items of the launch (K3 re-derives a lane's camera ray from its item index)
   uint32_t resolve_counts_written;  // 1: rt_resolve_kernel counts the written pixels (the phase kernels do not)
+  // ---- merged levels (rt_tuning.levels = RT_LEVELS_MERGED): ONE append-only queue; level k = its slice [*seg_lo, *seg_hi); nullptr otherwise
+  const uint32_t* seg_lo;
+  const uint32_t* seg_hi;
 };
 
 #define RT_QUEUE_QUADS 4u   // float4 per ray record

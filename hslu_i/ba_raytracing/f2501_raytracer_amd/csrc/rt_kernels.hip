@@ -2317,6 +2317,158 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_cost_kernel(RtDe
 // neighbouring surface points whatever pixel they belong to.  The image does not depend on the order
 // (integer pixel accumulation).
 // ------------------------------------------------------------------------------------------------
+// The children of a Whitted node: calculate_reflection (raytracer_renderer.rs:526-729) and calculate_refractions (:279-524), appended
+// to the ray queue (the same op sequence as the two blocks at the end of process_ray).  W0 = the node's weight with a reflection child's
+// own atten(t) already in it (:722-726); every lane of the wavefront calls this (idle lanes: hit = false).
+__device__ __forceinline__ void spawn_children(const RtDevScene& sc, const RtDevParams& P, bool hit, V3 d, const Surf& sf, const Mat& m, V3 W0,
+                                               float n_start, int depth, uint32_t pix, uint32_t mult) {
+  const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
+  const bool T = m.transmissive;
+  {
+    bool spawn = false;
+    V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
+    int cdepth = 0;
+    const bool R = (m.metallic > 0.0f) || T;
+    if (hit && (P.flags & RT_FLAG_REFLECTIONS) && R) {
+      float cos_theta = dot(d, sf.n);
+      bool inside = cos_theta < 0.0f;
+      V3 inormal = inside ? -sf.n : sf.n;
+      float n2 = inside ? m.ior : P.air_ior;
+      float eta = inside ? (n2 / n_start) : (n_start / n2);
+      float cos_i = fabsf(cos_theta);
+      float sin2 = eta * eta * (1.0f - cos_i * cos_i);
+      bool tir = sin2 >= 1.0f;
+      bool reflective = (m.metallic > 0.0f) || (T && tir);
+      cdepth = depth < 0 ? (int)P.max_depth_reflection : (depth > 0 ? depth - 1 : 0);
+      if (reflective && cdepth > 0) {
+        V3 rr = normalize(reflected(d, sf.n));
+        V3 Rf = fresnel_reflectance(m, inormal, -d, n_start);
+        spawn = true;
+        co = sf.p + rr * epsv;
+        cd = rr;
+        cW = W0 * Rf;
+      }
+    }
+    queue_push(P, spawn, co, cd, n_start, cW, cdepth, KIND_REFL, pix, mult);
+  }
+  {
+    bool spawn = false;
+    V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
+    int cdepth = 0;
+    float cior = 0.0f;
+    if (hit && (P.flags & RT_FLAG_REFRACTIONS) && T) {
+      float cos_theta = dot(d, sf.n);
+      bool inside = cos_theta <= 0.0f;
+      V3 inormal = inside ? -sf.n : sf.n;
+      float n2 = inside ? m.ior : P.air_ior;
+      float eta = inside ? (n2 / n_start) : (n_start / n2);
+      float inv_eta = 1.0f / eta;
+      V3 Rf = fresnel_reflectance(m, inormal, d, inv_eta);
+      V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
+      V3 nn = -inormal;  // ultraviolet refracted(n = -inormal, eta = 1/eta)
+      float ndi = dot(nn, d);
+      float kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
+      float op = m.opacity;
+      int step = (op < 0.5f) ? 2 : 1;
+      int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
+      cdepth = depth < 0 ? (int)P.max_depth_refraction / fac : (depth > step ? depth - step : 0);
+      if (!(kk < 0.0f) && cdepth > 0) {  // kk < 0: zero vector -> NaN direction -> miss (deviation D2)
+        float sq = inv_eta * ndi + __builtin_sqrtf(kk);
+        V3 q = normalize(d * inv_eta - nn * sq);
+        spawn = true;
+        co = sf.p + q * epsv;
+        cd = q;
+        cW = (W0 * (m.boost + 1.0f)) * Tr;
+        cior = n2;
+      }
+    }
+    queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, pix, mult);
+  }
+}
+
+// The same children, appended with ONE atomic per WORKGROUP (both kinds together) instead of two per wavefront: every queue slot comes
+// from one counter, and returning atomics on one address retire at ~3 ns each whatever else the GPU does -- two per wavefront were
+// 6.9 M atomics = 20 ms of a 4K frame's trace launches (profiles/r04_phase_split.md, r04k).  Called by all 256 threads of the workgroup
+// the same number of times (two barriers); lds = 2 x 8 dwords, used alternately (`parity`) so that a wavefront that runs ahead into
+// the next call does not overwrite what a slower one still reads.
+__device__ __forceinline__ void spawn_children_block(const RtDevScene& sc, const RtDevParams& P, bool hit, V3 d, const Surf& sf, const Mat& m,
+                                                     V3 W0, float n_start, int depth, uint32_t pix, uint32_t mult, uint32_t* lds, uint32_t parity) {
+  const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
+  const bool T = m.transmissive;
+  // ---- which children exist: the conditions of calculate_reflection (:526-729) and calculate_refractions (:279-524)
+  bool s_refl = false, s_refr = false;
+  int d_refl = 0, d_refr = 0;
+  float cos_theta = dot(d, sf.n);
+  if (hit && (P.flags & RT_FLAG_REFLECTIONS) && ((m.metallic > 0.0f) || T)) {
+    bool inside = cos_theta < 0.0f;
+    float n2 = inside ? m.ior : P.air_ior;
+    float eta = inside ? (n2 / n_start) : (n_start / n2);
+    float cos_i = fabsf(cos_theta);
+    float sin2 = eta * eta * (1.0f - cos_i * cos_i);
+    bool reflective = (m.metallic > 0.0f) || (T && sin2 >= 1.0f);
+    d_refl = depth < 0 ? (int)P.max_depth_reflection : (depth > 0 ? depth - 1 : 0);
+    s_refl = reflective && d_refl > 0;
+  }
+  float inv_eta = 1.0f, ndi = 0.0f, kk = 0.0f, n2r = 0.0f;
+  V3 inormal_r = sf.n;
+  if (hit && (P.flags & RT_FLAG_REFRACTIONS) && T) {
+    bool inside = cos_theta <= 0.0f;
+    inormal_r = inside ? -sf.n : sf.n;
+    n2r = inside ? m.ior : P.air_ior;
+    float eta = inside ? (n2r / n_start) : (n_start / n2r);
+    inv_eta = 1.0f / eta;
+    ndi = dot(-inormal_r, d);
+    kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
+    float op = m.opacity;
+    int step = (op < 0.5f) ? 2 : 1;
+    int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
+    d_refr = depth < 0 ? (int)P.max_depth_refraction / fac : (depth > step ? depth - step : 0);
+    s_refr = !(kk < 0.0f) && d_refr > 0;  // kk < 0: zero vector -> NaN direction -> miss (deviation D2)
+  }
+  // ---- one reservation for the workgroup
+  const lanemask m1 = wave_ballot(s_refl), m2 = wave_ballot(s_refr);
+  const uint32_t n1 = (uint32_t)__popcll(m1), n2c = (uint32_t)__popcll(m2);
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t* L = lds + parity * 8u;
+  if ((threadIdx.x & 63u) == 0) L[wave] = n1 + n2c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = L[0] + L[1] + L[2] + L[3];
+    L[4] = tot ? atomicAdd(P.q_out_count, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = L[4];
+  for (uint32_t w = 0; w < wave; w++) base += L[w];
+  base = __builtin_amdgcn_readfirstlane(base);
+  auto store = [&](uint32_t i, V3 o, V3 dd, float ns, V3 Wt, int dep, int kind) {
+    if (i < P.q_capacity) {
+      float4* rec = P.q_out + (size_t)i * RT_QUEUE_QUADS;
+      stream_store4(rec + 0, make_float4(o.x, o.y, o.z, ns));
+      stream_store4(rec + 1, make_float4(dd.x, dd.y, dd.z, __int_as_float(pack_dkm(dep, kind, mult))));
+      stream_store4(rec + 2, make_float4(Wt.x, Wt.y, Wt.z, __uint_as_float(pix)));
+    } else {
+      atomicAdd(P.q_overflow, 1u);
+    }
+  };
+  if (s_refl) {
+    bool inside = cos_theta < 0.0f;
+    V3 inormal = inside ? -sf.n : sf.n;
+    V3 rr = normalize(reflected(d, sf.n));
+    V3 Rf = fresnel_reflectance(m, inormal, -d, n_start);
+    store(base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)), sf.p + rr * epsv, rr, n_start, W0 * Rf, d_refl,
+          KIND_REFL);
+  }
+  if (s_refr) {
+    V3 Rf = fresnel_reflectance(m, inormal_r, d, inv_eta);
+    V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
+    V3 nn = -inormal_r;  // ultraviolet refracted(n = -inormal, eta = 1/eta)
+    float sq = inv_eta * ndi + __builtin_sqrtf(kk);
+    V3 q = normalize(d * inv_eta - nn * sq);
+    store(base + n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u)), sf.p + q * epsv, q, n2r,
+          (W0 * (m.boost + 1.0f)) * Tr, d_refr, KIND_REFR);
+  }
+}
+
 __device__ __forceinline__ RayIn load_queued_ray(const RtDevParams& P, size_t j) {
   const float4* rec = P.q_in + j * RT_QUEUE_QUADS;
   float4 a = stream_load4(rec + 0), b = stream_load4(rec + 1), c = stream_load4(rec + 2);
@@ -2349,15 +2501,21 @@ __device__ __forceinline__ uint32_t morton_expand10(uint32_t v) {
   return v;
 }
 
-template <bool CULL>
+// SPAWN (merged levels, rt_tuning.levels): the level's rays are the slice [*seg_lo, *seg_hi) of ONE append-only queue, and the kernel
+// that finds a ray's hit also appends its children behind the slice -- so the next level can be traced at once, without waiting for this
+// level to be shaded, and ALL levels are shaded by one launch in one hit-point order.
+template <bool CULL, bool SPAWN>
 __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevParams& P, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
   wave_flush_init(P, lds_cnt);
   // how many rays this level holds is only known on the device (the kernel before appended them)
-  uint32_t n = uload(P.q_in_count);
+  uint32_t n = SPAWN ? uload(P.seg_hi) : uload(P.q_in_count);
   n = n < P.q_capacity ? n : P.q_capacity;
-  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+  uint32_t first = SPAWN ? uload(P.seg_lo) : 0u;
+  first = first < n ? first : n;
+  uint32_t spawn_parity = 0u;
+  for (uint32_t base = first + blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + threadIdx.x;
     const bool have = i < n;
     RayIn r = idle_ray();
@@ -2408,6 +2566,18 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
       // what rt_sort_place_kernel needs, 8 coalesced bytes per ray (it would pull the 64-byte record for them otherwise)
       P.sort_slot[i] = make_uint2(hit ? bucket : 0xFFFFFFFFu, rank);
     }
+    if (SPAWN) {  // (every wavefront of the workgroup: the reservation below has barriers)
+      Hit hh = h;
+      hh.id = hit ? h.id : 0;
+      Surf sf;
+      sf.p = mk(0, 0, 0), sf.n = mk(0, 0, 1), sf.mat = 0;
+      if (hit) sf = surface_of(sc, hh, r.o, d);
+      const Mat m = load_mat(sc, sf.mat);
+      V3 W0 = r.Wt;
+      if (r.kind == KIND_REFL) W0 = W0 * atten(h.t);  // (a reflection child's weight carries its own atten(t), :722-726)
+      spawn_children_block(sc, P, hit, d, sf, m, W0, r.n_start, r.depth, r.pix, r.mult, (uint32_t*)(lds_cnt + 20), spawn_parity);
+      spawn_parity ^= 1u;
+    }
   }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
@@ -2415,9 +2585,16 @@ __device__ __forceinline__ void trace_body(const RtDevScene& sc, const RtDevPara
 __global__ __launch_bounds__(256, 4) void rt_trace_kernel(RtDevScene sc, RtDevParams P) {
   __shared__ unsigned long long lds_cnt[20];  // 15 counters (wave_flush), [16..19]: wave start times (cost calibration)
   if (P.flags & RT_FLAG_BACKFACE_CULLING)
-    trace_body<true>(sc, P, lds_cnt);
+    trace_body<true, false>(sc, P, lds_cnt);
   else
-    trace_body<false>(sc, P, lds_cnt);
+    trace_body<false, false>(sc, P, lds_cnt);
+}
+__global__ __launch_bounds__(256, 4) void rt_trace_spawn_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ unsigned long long lds_cnt[28];  // [20..27]: the workgroup's queue reservation (spawn_children_block), 2 x 8 dwords
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    trace_body<true, true>(sc, P, lds_cnt);
+  else
+    trace_body<false, true>(sc, P, lds_cnt);
 }
 
 template <bool CULL>
@@ -2427,9 +2604,10 @@ __device__ __forceinline__ void shade_body(const RtDevScene& sc, const RtDevPara
   wave_init(wv);
   wave_flush_init(P, lds_cnt);
   const uint32_t n = uload(P.sort_hits);  // the rays of this level that hit something, in hit-point order (misses are not listed)
+  const uint32_t first = P.seg_lo ? uload(P.seg_lo) : 0u;  // (pipelined levels: the level's sorted positions start at its slice of the queue)
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t jr = i < n ? P.sh_idx[i] : 0xFFFFFFFFu;
+    const uint32_t jr = i < n ? P.sh_idx[first + i] : 0xFFFFFFFFu;
     const bool have = jr != 0xFFFFFFFFu;
     RayIn r = idle_ray();
     Hit h;
@@ -2824,7 +3002,10 @@ int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs
 
 int rt_launch_trace(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) n_wgs = 1;
-  hipLaunchKernelGGL(rt_trace_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  if (p.seg_lo)
+    hipLaunchKernelGGL(rt_trace_spawn_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else
+    hipLaunchKernelGGL(rt_trace_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 

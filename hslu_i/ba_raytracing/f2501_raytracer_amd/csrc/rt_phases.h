@@ -400,70 +400,8 @@ __device__ __forceinline__ void classify_wave(const RtDevScene& sc, const RtDevP
     if (hit && !T) own_x = __float2ll_rn(c.x * RT_ACC_SCALE), own_y = __float2ll_rn(c.y * RT_ACC_SCALE), own_z = __float2ll_rn(c.z * RT_ACC_SCALE);
     if (L0 && hit) P.acc[4 * (size_t)it.pix + 3] = 1;  // the pixel is written (any sample hit: antialiased_raytrace :1001-1015)
   }
-  // ---- children: calculate_reflection :526-729, calculate_refractions :279-524 (as process_ray) ----------------------------
-  if (P.q_out) {
-    const V3 epsv = mk(P.eps_distance, P.eps_distance, P.eps_distance);
-    {
-      bool spawn = false;
-      V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
-      int cdepth = 0;
-      const bool R = (m.metallic > 0.0f) || T;
-      if (hit && (P.flags & RT_FLAG_REFLECTIONS) && R) {
-        float cos_theta = dot(it.d, it.sf.n);
-        bool inside = cos_theta < 0.0f;
-        V3 inormal = inside ? -it.sf.n : it.sf.n;
-        float n2 = inside ? m.ior : P.air_ior;
-        float eta = inside ? (n2 / it.n_start) : (it.n_start / n2);
-        float cos_i = fabsf(cos_theta);
-        float sin2 = eta * eta * (1.0f - cos_i * cos_i);
-        bool tir = sin2 >= 1.0f;
-        bool reflective = (m.metallic > 0.0f) || (T && tir);
-        cdepth = it.depth < 0 ? (int)P.max_depth_reflection : (it.depth > 0 ? it.depth - 1 : 0);
-        if (reflective && cdepth > 0) {
-          V3 rr = normalize(reflected(it.d, it.sf.n));
-          V3 Rf = fresnel_reflectance(m, inormal, -it.d, it.n_start);
-          spawn = true;
-          co = it.sf.p + rr * epsv;
-          cd = rr;
-          cW = it.W0 * Rf;
-        }
-      }
-      queue_push(P, spawn, co, cd, it.n_start, cW, cdepth, KIND_REFL, it.pix, it.mult);
-    }
-    {
-      bool spawn = false;
-      V3 co = mk(0, 0, 0), cd = mk(0, 0, 1), cW = mk(0, 0, 0);
-      int cdepth = 0;
-      float cior = 0.0f;
-      if (hit && (P.flags & RT_FLAG_REFRACTIONS) && T) {
-        float cos_theta = dot(it.d, it.sf.n);
-        bool inside = cos_theta <= 0.0f;
-        V3 inormal = inside ? -it.sf.n : it.sf.n;
-        float n2 = inside ? m.ior : P.air_ior;
-        float eta = inside ? (n2 / it.n_start) : (it.n_start / n2);
-        float inv_eta = 1.0f / eta;
-        V3 Rf = fresnel_reflectance(m, inormal, it.d, inv_eta);
-        V3 Tr = mk(1.0f - Rf.x, 1.0f - Rf.y, 1.0f - Rf.z);
-        V3 nn = -inormal;
-        float ndi = dot(nn, it.d);
-        float kk = 1.0f - inv_eta * inv_eta * (1.0f - ndi * ndi);
-        float op = m.opacity;
-        int step = (op < 0.5f) ? 2 : 1;
-        int fac = (op <= 0.3f) ? 3 : ((op < 0.5f) ? 2 : 1);
-        cdepth = it.depth < 0 ? (int)P.max_depth_refraction / fac : (it.depth > step ? it.depth - step : 0);
-        if (!(kk < 0.0f) && cdepth > 0) {  // kk < 0: zero vector -> NaN direction -> miss (deviation D2)
-          float s = inv_eta * ndi + __builtin_sqrtf(kk);
-          V3 q = normalize(it.d * inv_eta - nn * s);
-          spawn = true;
-          co = it.sf.p + q * epsv;
-          cd = q;
-          cW = (it.W0 * (m.boost + 1.0f)) * Tr;
-          cior = n2;
-        }
-      }
-      queue_push(P, spawn, co, cd, cior, cW, cdepth, KIND_REFR, it.pix, it.mult);
-    }
-  }
+  // ---- children: calculate_reflection :526-729, calculate_refractions :279-524 -------------------------------------------------
+  if (P.q_out) spawn_children(sc, P, hit, it.d, it.sf, m, it.W0, it.n_start, it.depth, it.pix, it.mult);
   // every hit point casts lights x N shadow rays in the reference (raytracer.rs:24); counted once, here
   wv.cnt_shadow += sc.n_lights * N * (P.weighted ? wave_sum(hit ? it.mult : 0u) : (uint32_t)__popcll(hit_m));
 

@@ -93,12 +93,15 @@ __global__ __launch_bounds__(256) void rt_sort_bases_kernel(uint32_t* __restrict
 }
 
 __global__ __launch_bounds__(256) void rt_sort_place_kernel(RtDevParams P) {
-  uint32_t n = *(const uint32_t*)P.q_in_count;
+  // the level's rays: the whole queue, or (pipelined levels) its slice [*seg_lo, *seg_hi), whose sorted positions start at seg_lo too
+  uint32_t n = P.seg_hi ? *P.seg_hi : *(const uint32_t*)P.q_in_count;
   n = n < P.q_capacity ? n : P.q_capacity;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+  uint32_t first = P.seg_lo ? *P.seg_lo : 0u;
+  first = first < n ? first : n;
+  for (uint32_t i = first + blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint2 br = P.sort_slot[i];  // {bucket (all ones: a miss, not shaded), rank inside the bucket}
     if (br.x == 0xFFFFFFFFu) continue;
-    P.sh_idx[P.sort_tile[br.x / RT_SORT_TILE] + P.sort_offs[br.x] + br.y] = i;
+    P.sh_idx[first + P.sort_tile[br.x / RT_SORT_TILE] + P.sort_offs[br.x] + br.y] = i;
   }
 }
 

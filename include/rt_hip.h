@@ -155,7 +155,20 @@ typedef struct rt_tuning {
    * work item of the dominant kernels is a (wavefront, light) set, a fifth of a fused wavefront's.  Same integers in the pixel
    * accumulator, hence the same frame.  0 = the library's choice for the frame shape. */
   uint32_t phases;
+  /* How the levels of a frame's ray tree are run (RT_LEVELS_*; fused kernels only).  CHAINED: per level trace -> sort -> shade,
+   * the shade kernel appending the next level's rays.  MERGED: the kernel that finds a ray's hit also appends its children, so the
+   * levels are traced back to back (level k+1 does not wait for level k to be shaded) and ALL levels are then shaded by ONE launch in
+   * ONE hit-point order: one drain instead of one per level, and rays of every depth that hit neighbouring points share a wavefront.
+   * PIPELINED: the levels are traced back to back as in MERGED, each sorted on its own, and level k is shaded -- on one of two streams
+   * of the library's, alternately -- as soon as it has been traced and sorted: the trace launches (latency bound) run under the shade
+   * launches (issue bound), and the head of level k+1's shading fills the compute units the drain of level k's leaves idle.
+   * Same integer pixel sums, same frame.  0 = the library's choice. */
+  uint32_t levels;
 } rt_tuning;
+#define RT_LEVELS_DEFAULT 0u
+#define RT_LEVELS_CHAINED 1u
+#define RT_LEVELS_MERGED 2u
+#define RT_LEVELS_PIPELINED 3u
 #define RT_PHASES_DEFAULT 0u
 #define RT_PHASES_FUSED 1u
 #define RT_PHASES_SPLIT 2u

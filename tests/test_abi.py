@@ -44,7 +44,7 @@ def test_ctypes_layout_matches_header(tmp_path):
         " sizeof(rt_stats), sizeof(rt_bvh_info), offsetof(rt_params, aa_offsets), offsetof(rt_params, cloud_sets),"
         " offsetof(rt_params, traversal), offsetof(rt_params, tuning), offsetof(rt_scene_desc, bvh), sizeof(rt_gather_info),"
         " offsetof(rt_stats, rays_traced), offsetof(rt_stats, gather_ms), offsetof(rt_stats, notes), offsetof(rt_stats, queue_bytes),"
-        " offsetof(rt_params, tuning) + offsetof(rt_tuning, phases)); return 0;}\n")
+        " offsetof(rt_params, tuning) + offsetof(rt_tuning, levels)); return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -52,7 +52,7 @@ def test_ctypes_layout_matches_header(tmp_path):
             C.sizeof(_abi.rt_bvh_info), _abi.rt_params.aa_offsets.offset, _abi.rt_params.cloud_sets.offset,
             _abi.rt_params.traversal.offset, _abi.rt_params.tuning.offset, _abi.rt_scene_desc.bvh.offset,
             C.sizeof(_abi.rt_gather_info), _abi.rt_stats.rays_traced.offset, _abi.rt_stats.gather_ms.offset,
-            _abi.rt_stats.notes.offset, _abi.rt_stats.queue_bytes.offset, _abi.rt_params.tuning.offset + _abi.rt_tuning.phases.offset]
+            _abi.rt_stats.notes.offset, _abi.rt_stats.queue_bytes.offset, _abi.rt_params.tuning.offset + _abi.rt_tuning.levels.offset]
     assert got == want
 
 

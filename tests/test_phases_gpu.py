@@ -117,3 +117,55 @@ def test_split_streaming_frames_equal_the_fused_frames_bit_for_bit(key):
     a3, _, s3 = gpu_render(cfg, flat, aux=False, chunk_log2=20, **SPLIT)
     assert np.array_equal(a3, a) and all(s3[k] == s[k] for k in COUNTS)
     print(f"{key}: split {s['kernel_ms']:.1f} ms, fused {t['kernel_ms']:.1f} ms")
+
+
+MERGED = dict(levels=_abi.RT_LEVELS_MERGED)
+PIPELINED = dict(levels=_abi.RT_LEVELS_PIPELINED)
+CHAINED = dict(levels=_abi.RT_LEVELS_CHAINED)
+
+
+@pytest.mark.parametrize("MODE", [MERGED, PIPELINED], ids=["merged", "pipelined"])
+def test_merged_levels_against_the_oracle_and_the_chained_schedule(MODE):
+    """rt_tuning.levels = RT_LEVELS_MERGED: rt_trace_spawn_kernel appends a ray's children where its hit is found, the levels are traced
+    back to back and ONE shade launch handles the hits of all levels in one hit-point order.  The pixel sums are the same integers
+    whatever the order: same bits as the chained schedule, and green against the oracle."""
+    cfg = RenderConfig.from_features(["realistic", "high_quality", "anti_aliasing_randomness", "anti_aliasing_rotation_scale"],
+                                     n_cloud_sets=32, depth_override=4)
+    flat = scenes.test_scene(cfg).flatten()
+    win = (427, 171, 45, 37)
+    a, p, s = gpu_render(cfg, flat, win, **MODE)
+    b, q, t = gpu_render(cfg, flat, win, **CHAINED)
+    assert np.array_equal(a, b) and np.array_equal(p["rgb"].view(np.uint32), q["rgb"].view(np.uint32))
+    assert all(s[k] == t[k] for k in COUNTS)
+    argb_o, po, so = oracle_lib.render(flat, cfg, window=win)
+    assert np.array_equal(p["hit_id"], po["hit_id"]) and float(np.abs(p["rgb"] - po["rgb"]).max()) <= RGB_TOL
+    assert all(s[k] == so[k] for k in COUNTS[:5])
+    # deep trees, forced small batches (queues that must grow), one chain / two chains, linear scan, culling
+    cfg = RenderConfig.from_features(["realistic", "anti_aliasing", "soft_shadows"], depth_override=7, n_cloud_sets=16)
+    flat = scenes.test_scene(cfg).flatten()
+    win = (300, 200, 96, 64)
+    ref, pr, sr = gpu_render(cfg, flat, win, **CHAINED)
+    for kw in (dict(), dict(chunk_log2=10), dict(sub_frames=1), dict(sub_frames=2), dict(shadow_candidate_cap=_abi.RT_CAND_CAP_NONE)):
+        a, p, s = gpu_render(cfg, flat, win, **MODE, **kw)
+        assert np.array_equal(a, ref) and np.array_equal(p["rgb"].view(np.uint32), pr["rgb"].view(np.uint32)), kw
+        assert all(s[k] == sr[k] for k in COUNTS), kw
+    a, p, s = gpu_render(cfg, flat, win, traversal=_abi.RT_TRAVERSAL_LINEAR, **MODE)
+    b, q, t = gpu_render(cfg, flat, win, traversal=_abi.RT_TRAVERSAL_LINEAR, **CHAINED)
+    assert np.array_equal(a, b) and all(s[k] == t[k] for k in COUNTS)
+
+
+@pytest.mark.parametrize("MODE", [MERGED, PIPELINED], ids=["merged", "pipelined"])
+@pytest.mark.parametrize("key", ["c4", "c4d21", "c5"])
+def test_merged_levels_full_frames_equal_the_chained_frames_bit_for_bit(key, MODE):
+    cfg, flat, _ = bench.build_workload(key)
+    a, p, s = gpu_render(cfg, flat, **MODE)
+    b, q, t = gpu_render(cfg, flat, **CHAINED)
+    assert all(s[k] == t[k] for k in COUNTS), (s, t)
+    assert np.array_equal(p["rgb"].view(np.uint32), q["rgb"].view(np.uint32))
+    assert np.array_equal(a, b)
+    a3 = np.zeros_like(a)
+    for rank in range(3):
+        ar, _, _ = gpu_render(cfg, flat, n_ranks=3, rank=rank, aux=False, **MODE)
+        a3 |= ar
+    assert np.array_equal(a3, a)
+    print(f"{key}: {MODE} {s['kernel_ms']:.1f} ms, chained {t['kernel_ms']:.1f} ms (first frames of their shapes: verified, rendered twice if the queues had to grow)")

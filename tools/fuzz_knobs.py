@@ -71,6 +71,8 @@ def run(first, last):
                 knobs["no_aa_dedup"] = 1
             if secondary and r.random() < 0.3:  # (the phase-split pipeline adds the same fixed-point terms: frames with secondary rays are the same bits)
                 knobs["phases"] = _abi.RT_PHASES_SPLIT
+            if secondary and r.random() < 0.5:  # how the levels of the ray tree are scheduled
+                knobs["levels"] = int(r.integers(1, 4))
             if os.environ.get("FUZZ_VERBOSE"):
                 print(f"{what}: {knobs}")
             a, p, s = T.gpu_render(cfg, flat, win, **knobs)

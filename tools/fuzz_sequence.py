@@ -88,6 +88,8 @@ def run(first, last):
                 tuning["no_cell_lists"] = 1
             if r.random() < 0.25:
                 tuning["phases"] = _abi.RT_PHASES_SPLIT
+            if secondary and r.random() < 0.5:
+                tuning["levels"] = int(r.integers(1, 4))
             p, keep = _abi.make_params(cfg, window=win, n_ranks=n_ranks, rank=rank, tuning=tuning)
             # reference: a fresh scene handle, this frame alone
             ds0 = DeviceScene(flat, 0)

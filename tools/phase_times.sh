@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 [ -n "$LIB" ] && export RT_HIP_LIB=$R/hslu_i/ba_raytracing/f2501_raytracer_amd/$LIB
 OUT=$R/gpurun_out/${TAG}_${WL}_p${PH}
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 10 --warmup 2 --in-flight ${INFLIGHT:-1} --sub-frames ${SUBF:-1} --no-cpu-baseline --no-boundary-costs --no-other-workloads --workload $WL --phases $PH > $OUT.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 10 --warmup 2 --in-flight ${INFLIGHT:-1} --sub-frames ${SUBF:-1} --no-cpu-baseline --no-boundary-costs --no-other-workloads --workload $WL --phases $PH --levels ${LEVELS:-0} > $OUT.log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 echo "== $TAG $WL phases=$PH lib=${LIB:-librt_hip.so}: $(python3 -c "import json,sys; d=json.loads(open('$OUT.log').read().strip().splitlines()[-1]); print('%.3f ms/frame' % d['ms_per_step'])" 2>/dev/null)"
 python3 - "$f" <<'PY'
