@@ -854,7 +854,16 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
   const bool hard = (secondary || split || defer) && P.light_mult > 1 && P.light_mult <= 64 && P.traversal == RT_TRAVERSAL_BVH && s->dev.n_triangles && P.cand_cap != 0;
   if (!hard && P.light_mult > 1) s->notes |= RT_NOTE_HARD_PAIRS_OFF;
   // merged levels (rt_tuning.levels): every level traced first (the trace kernel appends the children), then ONE sort and ONE shade launch
-  const uint32_t levels_mode = (secondary && !split) ? rt_levels_mode(s->levels_wanted) : RT_LEVELS_CHAINED;
+  uint32_t levels_mode = (secondary && !split) ? rt_levels_mode(s->levels_wanted) : RT_LEVELS_CHAINED;
+  if (levels_mode == RT_LEVELS_MERGED && s->levels_wanted == RT_LEVELS_DEFAULT) {
+    // The merged queue holds every level of the tree at once (config 4: 5.0 GB against the 2.9 GB of two alternating queues).  Where a
+    // third of the free memory (plus what this scene's workspaces already hold) does not take about four times the primary work items,
+    // the library's choice is the chained schedule rather than a frame cut into batches.
+    size_t free_b = 0, total_b = 0, held = 0;
+    for (const auto& o : s->ws) held += o.bytes();
+    const uint64_t want = (uint64_t)total_wgs * 256u * 4u * (64u + 12u);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > (free_b + held) / 3u) levels_mode = RT_LEVELS_CHAINED;
+  }
   const bool pipelined = levels_mode == RT_LEVELS_PIPELINED;
   const bool merged = levels_mode == RT_LEVELS_MERGED || pipelined;  // (one append-only queue per chain, children spawned by the trace kernel)
   const uint32_t n_cnt = RT_CNT_TOTAL(levels);

@@ -1171,7 +1171,9 @@ def test_streaming_frames_are_enqueued_without_waiting_for_the_gpu():
     assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), fb, C.c_size_t(nbytes), 2) == 0
     ref, _, st = gpu_render(cfg, flat, aux=False)
     assert np.array_equal(got, ref)
-    assert 0 < st["queue_bytes"] <= 4 << 30, st["queue_bytes"]
+    # (merged levels, the default since round 4: ONE queue holds the rays of every level -- 58.5 M for this frame, 5.0 GB with its sort
+    # workspace -- where the chained schedule alternated between two queues of one level each, 2.9 GB)
+    assert 0 < st["queue_bytes"] <= 6 << 30, st["queue_bytes"]
     g.close()
     ds.close()
     assert hip.hipStreamDestroy(stream) == 0 and hip.hipFree(fb) == 0
