@@ -87,6 +87,7 @@ void rt_scene_destroy(rt_scene* s) {
         if (l.shade_done[k]) (void)hipEventDestroy(l.shade_done[k]);
       }
       for (hipEvent_t e : l.level_ev) (void)hipEventDestroy(e);
+      if (l.hit_ev) (void)hipEventDestroy(l.hit_ev);
       for (DevBuf* b : {&l.queues, &l.qcount, &l.trace_ws, &l.hard, &l.hitrec, &l.sets}) b->release();
     }
   }
@@ -1024,7 +1025,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         if (rc == RT_OK) rc = w.lane[j].trace_ws.ensure((size_t)q_sort_cap * 12 + (size_t)n_buckets * 8 + (n_buckets / RT_SORT_TILE) * 4 + 256);
       }
       if (rc == RT_OK && hard) rc = w.lane[j].hard.ensure(((size_t)s->hard_cap + 64u) * 4u * sizeof(float4));
-      if (rc == RT_OK && split) rc = w.lane[j].hitrec.ensure(hitrec_items * 8u);
+      if (rc == RT_OK && (split || merged)) rc = w.lane[j].hitrec.ensure(hitrec_items * 8u);
       if (rc == RT_OK && split) rc = w.lane[j].sets.ensure((size_t)set_cap * (32u + 256u + 12u + 1u) + 256u);
     }
     if (rc == RT_ERR_OOM && s->q_cap > (1u << 16) && attempt < 12) {
@@ -1158,6 +1159,28 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
         if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
         trace_point(st, "rt_classify0_kernel: first workgroup, workgroups, set capacity", w0, nw, set_cap);
         if ((rc = run_sets(0, nw * 4u * s->dev.n_lights)) != RT_OK) return rc;
+      } else if (merged) {
+        // The camera rays' hits and children first (rt_hit_spawn_kernel: 44 VGPRs, no scratch), so that the levels below can be traced
+        // at once -- latency-bound launches -- while the hits are SHADED on a stream of the chain's (rt_primary_pre_kernel: issue bound).
+        rt_scene::Lane& L = w.lane[j];
+        if ((size_t)nw * 256u > hitrec_items) return fail(RT_ERR_HIP, "internal: primary batch of %u workgroups exceeds the hit-record buffer", nw);
+        if (!L.shade_stream[0]) HIP_TRY(hipStreamCreateWithFlags(&L.shade_stream[0], hipStreamNonBlocking));
+        if (!L.shade_done[0]) HIP_TRY(hipEventCreateWithFlags(&L.shade_done[0], hipEventDisableTiming));
+        if (!L.hit_ev) HIP_TRY(hipEventCreateWithFlags(&L.hit_ev, hipEventDisableTiming));
+        Q.hitrec = (uint2*)L.hitrec.p;
+        Q.hit_spawns = 1u;
+        e = (hipError_t)rt_launch_hit(s->dev, Q, nw, st);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(st, "rt_hit_spawn_kernel: first workgroup, workgroups, queue capacity", w0, nw, q_sort_cap);
+        HIP_TRY(hipEventRecord(L.hit_ev, st));
+        HIP_TRY(hipStreamWaitEvent(L.shade_stream[0], L.hit_ev, 0));
+        joiner.shading = true;
+        RtDevParams Pp = Q;
+        Pp.q_out = nullptr, Pp.q_out_count = nullptr, Pp.hit_spawns = 0u;
+        e = (hipError_t)rt_launch_primary(s->dev, Pp, nw, L.shade_stream[0]);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        trace_point(L.shade_stream[0], "rt_primary_pre_kernel: first workgroup, workgroups", w0, nw);
+        Q.hit_spawns = 0u;
       } else {
         e = (hipError_t)rt_launch_primary(s->dev, Q, nw, st);
         if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -1166,7 +1189,8 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
       if (merged) {
         // ---- every level traced first: rt_trace_spawn_kernel finds the hits of the slice [seg[k], seg[k + 1]) of the chain's ONE queue and
         // appends their children behind it; the slice's end is a stream-ordered snapshot of the queue's running total
-        if ((rc = run_hard(j, st)) != RT_OK) return rc;  // the pairs the primary launch deferred
+        // (no rt_hard_kernel in between: the camera rays are being shaded on the chain's shade stream meanwhile and defer pairs of their
+        // own; every deferred pair of the frame waits in the pair queue for the one launch behind the join)
         rt_scene::Lane& L = w.lane[j];
         uint32_t* total = counts[j] + RT_CNT_LEVEL(1);
         if (lane_batches[j] > 1) HIP_TRY(hipMemsetAsync(counts[j] + RT_CNT_SEG(levels, 0), 0, (size_t)(levels + 2u) * 4, st));
@@ -1222,6 +1246,7 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
           }
           joiner.shading = false;  // (joined on the device: the chain's stream now orders everything behind the shade launches)
         } else {
+          Q.hitrec = nullptr;
           // ---- MERGED: one hit-point order over the rays of all levels, one shade launch (no children: they exist already)
           Q.sort_hits = counts[j] + RT_CNT_HITS(levels, 1);
           const uint32_t g_all = guess ? grid_for(s->est[j][RT_CNT_LEVEL(1)], 256u, cap_wgs) : cap_wgs;
@@ -1231,6 +1256,9 @@ static int render_frame_impl(rt_scene* s, RtDevParams& P, hipStream_t stream, ui
           e = (hipError_t)rt_launch_shade(s->dev, Q, g_hits, st);
           if (e != hipSuccess) return fail(RT_ERR_HIP, "shade launch failed: %s", hipGetErrorString(e));
           trace_point(st, "rt_shade_kernel (all levels): workgroups, chain", g_hits, j);
+          HIP_TRY(hipEventRecord(L.shade_done[0], L.shade_stream[0]));  // join: the camera rays' shading
+          HIP_TRY(hipStreamWaitEvent(st, L.shade_done[0], 0));
+          joiner.shading = false;
         }
       }
       for (uint32_t k = 1; k <= levels && !merged; k++) {

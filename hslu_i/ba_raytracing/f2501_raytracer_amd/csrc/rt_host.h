@@ -96,6 +96,7 @@ struct rt_scene {
     hipStream_t shade_stream[2] = {nullptr, nullptr};
     hipEvent_t shade_done[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> level_ev;
+    hipEvent_t hit_ev = nullptr;      // merged levels: the camera rays' hits (and children) exist -- their shading may start on shade_stream[0]
   };
   struct StreamWs {
     Lane lane[RT_LANES];

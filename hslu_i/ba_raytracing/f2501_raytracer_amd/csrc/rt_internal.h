@@ -201,6 +201,7 @@ struct RtDevParams {
   // ---- merged levels (rt_tuning.levels = RT_LEVELS_MERGED): ONE append-only queue; level k = its slice [*seg_lo, *seg_hi); nullptr otherwise
   const uint32_t* seg_lo;
   const uint32_t* seg_hi;
+  uint32_t hit_spawns;  // rt_launch_hit: 1 = rt_hit_spawn_kernel (the camera rays' children are appended where their hits are found)
 };
 
 #define RT_QUEUE_QUADS 4u   // float4 per ray record

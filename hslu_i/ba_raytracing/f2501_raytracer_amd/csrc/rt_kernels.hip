@@ -2071,7 +2071,9 @@ __device__ __forceinline__ void acc_add_fixed(const RtDevParams& P, uint32_t pix
 // ------------------------------------------------------------------------------------------------
 // COST: the calibration variant of RT_TILE_ORDER_COST (wavefront run times per super-tile); a kernel of its own so that
 // the shipped kernels carry none of it.
-template <bool CULL, bool STREAM, bool COST = false>
+// PRE (merged levels): the camera rays' hits were found -- and their children appended -- by rt_hit_spawn_kernel; this launch only shades
+// them, concurrently with the trace launches of the levels below on another stream.
+template <bool CULL, bool STREAM, bool COST = false, bool PRE = false>
 __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevParams& P, float4* lds_rgbh,
                                              float* lds_stash, unsigned long long* lds_cnt) {
   Wave wv;
@@ -2148,7 +2150,12 @@ __device__ __forceinline__ void primary_body(const RtDevScene& sc, const RtDevPa
   Hit none;
   none.t = INFINITY;
   none.id = -1;
-  RayOut out = process_ray<CULL, false, STREAM>(sc, P, wv, pix_on, r, lds_stash, none);
+  if (PRE) {
+    const uint2 hr = P.hitrec[(size_t)blockIdx.x * 256u + threadIdx.x];
+    none.t = __uint_as_float(hr.x);
+    none.id = (int)hr.y;
+  }
+  RayOut out = process_ray<CULL, PRE, STREAM>(sc, P, wv, pix_on, r, lds_stash, none);
 
   // ---- per-pixel accumulation of the samples ----------------------------------------------------------
   V3 cs = out.contrib;  // = own * scale (c * scale, :974,:992)
@@ -2280,6 +2287,17 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_stream_kernel(Rt
     primary_body<true, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
   else
     primary_body<false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+}
+
+// merged levels: shading of the camera rays whose hits rt_hit_spawn_kernel found (no children here: they exist already)
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void rt_primary_pre_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ float4 lds_rgbh[256];
+  __shared__ __attribute__((aligned(16))) float lds_stash[RT_STASH_FIELDS * 256];
+  __shared__ unsigned long long lds_cnt[20];
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    primary_body<true, true, false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
+  else
+    primary_body<false, true, false, true>(sc, P, lds_rgbh, lds_stash, lds_cnt);
 }
 
 // calibration frames of RT_TILE_ORDER_COST (once per scene and frame shape): the same kernels + the per-super-tile timers.
@@ -2922,7 +2940,10 @@ bool rt_has_cost_kernel() { return RT_COST_KERNEL != 0; }
 
 int rt_launch_hit(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs, void* stream) {
   if (n_wgs == 0) return 0;
-  hipLaunchKernelGGL(rt_hit_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  if (p.hit_spawns)  // merged levels: the camera rays' children are appended where their hits are found
+    hipLaunchKernelGGL(rt_hit_spawn_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else
+    hipLaunchKernelGGL(rt_hit_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   return (int)hipGetLastError();
 }
 
@@ -2993,7 +3014,9 @@ int rt_launch_primary(const RtDevScene& sc, const RtDevParams& p, uint32_t n_wgs
     return (int)hipGetLastError();
   }
 #endif
-  if (p.acc)
+  if (p.acc && p.hitrec)  // (hits and children by rt_hit_spawn_kernel)
+    hipLaunchKernelGGL(rt_primary_pre_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
+  else if (p.acc)
     hipLaunchKernelGGL(rt_primary_stream_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);
   else
     hipLaunchKernelGGL(rt_primary_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream, sc, p);

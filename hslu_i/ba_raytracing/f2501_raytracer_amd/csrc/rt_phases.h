@@ -92,7 +92,9 @@ __device__ __forceinline__ RayIn primary_ray(const RtDevParams& P, const PixelMa
 }
 
 // ---- K1: camera ray -> nearest hit -> hit record ---------------------------------------------------------------------
-template <bool CULL>
+// SPAWN (merged levels of the fused pipeline): the children of the camera rays are appended here too, so that the levels below can be
+// traced while rt_primary_pre_kernel shades these hits on another stream.
+template <bool CULL, bool SPAWN = false>
 __device__ __forceinline__ void hit_body(const RtDevScene& sc, const RtDevParams& P, unsigned long long* lds_cnt) {
   Wave wv;
   wave_init(wv);
@@ -120,6 +122,15 @@ __device__ __forceinline__ void hit_body(const RtDevScene& sc, const RtDevParams
     if (P.aux_hit_id) P.aux_hit_id[pm.pix] = hit ? h.id : -1;
     if (P.aux_hit_t && hit) P.aux_hit_t[pm.pix] = h.t;
   }
+  if (SPAWN) {  // (all 256 threads: the workgroup's queue reservation has barriers)
+    Hit hh = h;
+    hh.id = hit ? h.id : 0;
+    Surf sf;
+    sf.p = mk(0, 0, 0), sf.n = mk(0, 0, 1), sf.mat = 0;
+    if (hit) sf = surface_of(sc, hh, r.o, d);
+    const Mat m = load_mat(sc, sf.mat);
+    spawn_children_block(sc, P, hit, d, sf, m, r.Wt, r.n_start, r.depth, r.pix, r.mult, (uint32_t*)(lds_cnt + 20), 0u);
+  }
   wave_flush(wv, P, 0ull, lds_cnt);
 }
 
@@ -129,6 +140,14 @@ __global__ __launch_bounds__(256, 8) void rt_hit_kernel(RtDevScene sc, RtDevPara
     hit_body<true>(sc, P, lds_cnt);
   else
     hit_body<false>(sc, P, lds_cnt);
+}
+
+__global__ __launch_bounds__(256, 8) void rt_hit_spawn_kernel(RtDevScene sc, RtDevParams P) {
+  __shared__ unsigned long long lds_cnt[28];  // [20..27]: the workgroup's queue reservation (spawn_children_block)
+  if (P.flags & RT_FLAG_BACKFACE_CULLING)
+    hit_body<true, true>(sc, P, lds_cnt);
+  else
+    hit_body<false, true>(sc, P, lds_cnt);
 }
 
 // ---- the hit of a work item, re-derived where it is needed (K2, K3) ------------------------------------------------------
