@@ -154,8 +154,8 @@ def test_merged_levels_against_the_oracle_and_the_chained_schedule(MODE):
     assert np.array_equal(a, b) and all(s[k] == t[k] for k in COUNTS)
 
 
-@pytest.mark.parametrize("MODE", [MERGED, PIPELINED], ids=["merged", "pipelined"])
-@pytest.mark.parametrize("key", ["c4", "c4d21", "c5"])
+@pytest.mark.parametrize("key,MODE", [("c4", MERGED), ("c4d21", MERGED), ("c5", MERGED), ("c4", PIPELINED)],
+                         ids=["c4-merged", "c4d21-merged", "c5-merged", "c4-pipelined"])
 def test_merged_levels_full_frames_equal_the_chained_frames_bit_for_bit(key, MODE):
     cfg, flat, _ = bench.build_workload(key)
     a, p, s = gpu_render(cfg, flat, **MODE)
