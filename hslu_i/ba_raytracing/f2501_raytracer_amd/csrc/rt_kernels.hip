@@ -2446,7 +2446,7 @@ __device__ __forceinline__ void spawn_children_block(const RtDevScene& sc, const
   // ---- one reservation for the workgroup
   const lanemask m1 = wave_ballot(s_refl), m2 = wave_ballot(s_refr);
   const uint32_t n1 = (uint32_t)__popcll(m1), n2c = (uint32_t)__popcll(m2);
-  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: the prefix loop below is a scalar loop)
   uint32_t* L = lds + parity * 8u;
   if ((threadIdx.x & 63u) == 0) L[wave] = n1 + n2c;
   __syncthreads();
@@ -2969,13 +2969,16 @@ int rt_launch_sets(const RtDevScene& sc, const RtDevParams& p, bool level0, int 
   if (n_wgs == 0) n_wgs = 1;
   const dim3 g(n_wgs), b(256);
   hipStream_t st = (hipStream_t)stream;
-  if (level0) {
-    if (cls == SET_ARRIVE) hipLaunchKernelGGL(rt_sets0_arrive_kernel, g, b, 0, st, sc, p);
-    else if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets0_list_kernel, g, b, 0, st, sc, p);
+  if (cls == SET_ARRIVE) {
+#if !RT_ARRIVE_INLINE
+    if (level0) hipLaunchKernelGGL(rt_sets0_arrive_kernel, g, b, 0, st, sc, p);
+    else hipLaunchKernelGGL(rt_sets_arrive_kernel, g, b, 0, st, sc, p);
+#endif
+  } else if (level0) {
+    if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets0_list_kernel, g, b, 0, st, sc, p);
     else hipLaunchKernelGGL(rt_sets0_walk_kernel, g, b, 0, st, sc, p);
   } else {
-    if (cls == SET_ARRIVE) hipLaunchKernelGGL(rt_sets_arrive_kernel, g, b, 0, st, sc, p);
-    else if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets_list_kernel, g, b, 0, st, sc, p);
+    if (cls == SET_LIST) hipLaunchKernelGGL(rt_sets_list_kernel, g, b, 0, st, sc, p);
     else hipLaunchKernelGGL(rt_sets_walk_kernel, g, b, 0, st, sc, p);
   }
   return (int)hipGetLastError();

@@ -643,9 +643,11 @@ __device__ __forceinline__ void sets_body(const RtDevScene& sc, const RtDevParam
     else                                                                                      \
       sets_body<false, L0, CLS>(sc, P, lds_fx, lds_cnt);                                      \
   }
+#if !RT_ARRIVE_INLINE  // (K2 finishes ARRIVE sets itself in the shipped build: their queue is never filled)
 RT_SETS_KERNEL(rt_sets0_arrive_kernel, true, SET_ARRIVE, RT_SETS_WAVES)
+RT_SETS_KERNEL(rt_sets_arrive_kernel, false, SET_ARRIVE, RT_SETS_WAVES)
+#endif
 RT_SETS_KERNEL(rt_sets0_list_kernel, true, SET_LIST, RT_SETS_WAVES)
 RT_SETS_KERNEL(rt_sets0_walk_kernel, true, SET_WALK, RT_SETS_WAVES)
-RT_SETS_KERNEL(rt_sets_arrive_kernel, false, SET_ARRIVE, RT_SETS_WAVES)
 RT_SETS_KERNEL(rt_sets_list_kernel, false, SET_LIST, RT_SETS_WAVES)
 RT_SETS_KERNEL(rt_sets_walk_kernel, false, SET_WALK, RT_SETS_WAVES)

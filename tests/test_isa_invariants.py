@@ -23,6 +23,10 @@ ALLOWED = {
     "rt_trace_kernel": 0,
     "rt_hard_kernel": 1,   # the stackless per-lane walk of incoherent (hit point, light) pairs: divergent by design
     "rt_flags_kernel": 1,  # the per-lane binary search for the triangle that owns a receiver cell
+    # merged levels
+    "rt_hit_spawn_kernel": 0,
+    "rt_trace_spawn_kernel": 0,
+    "rt_primary_pre_kernel": 0,
     # the phase-split pipeline (rt_phases.h)
     "rt_hit_kernel": 0,
     "rt_classify0_kernel": 0,
@@ -61,7 +65,7 @@ def test_render_kernels_have_no_divergent_loops():
 def test_walks_fetch_their_nodes_through_scalar_loads():
     bodies = _kernel_bodies(_asm_text())
     for name in ("rt_primary_kernel", "rt_primary_stream_kernel", "rt_shade_kernel", "rt_trace_kernel", "rt_flags_kernel", "rt_hit_kernel",
-                 "rt_classify0_kernel", "rt_classify_kernel"):
+                 "rt_classify0_kernel", "rt_classify_kernel", "rt_hit_spawn_kernel", "rt_trace_spawn_kernel", "rt_primary_pre_kernel"):
         assert "s_load_dwordx16" in bodies[name], f"{name}: no 64-byte scalar node fetch (a walk lost its uniformity)"
 
 
