@@ -18,7 +18,7 @@ kname = {"c1": "rt_primary_kernel", "c2": "rt_primary_kernel", "c3": "rt_primary
 src = os.path.join("gpurun_out", f"prof_{tag}_{wl}")
 os.makedirs("profiles", exist_ok=True)
 build_id = open(os.path.join(src, "build_id.txt")).read().split()[0]
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+ks = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1]  # (the newest run into this directory)
 shutil.copy(ks, os.path.join("profiles", f"{tag}_{wl}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(ks)))
 nf = os.path.join(src, "n_frames.txt")
@@ -30,7 +30,12 @@ avg_ms = float(kern["AverageNs"]) / 1e6
 frame_ms = float(kern["TotalDurationNs"]) / 1e6 / n_frames
 pmc = collections.OrderedDict()
 meta = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+newest = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):  # one file per pass: the newest run's
+    d = os.path.basename(os.path.dirname(os.path.dirname(f)))
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in sorted(newest.values()):
     agg = collections.defaultdict(float)
     n_disp = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
